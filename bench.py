@@ -1,0 +1,187 @@
+"""bench.py -- point-clouds/sec, forward+backward, ModelNet40-shaped 1024-point classification
+(BASELINE.json metric) on N MI355X GPUs of one node.
+
+A "step" is one training pass of the hot path over one batch of synthetic clouds:
+forward (FPS -> kNN grouping -> difference-wise attention -> transition MLPs -> head), the
+label-smoothed loss, backward, gradient all-reduce over RCCL when N > 1, and an Adam step.
+Workload at N=1: BASELINE configs[1] -- 1024 points, batch 64 per GPU, fp32 (weak scaling:
+per-GPU batch fixed).  Inputs are resident in HBM before the timed region.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  Extra objects: "roofline" for the dominant kernel (HIP events on
+the launch stream around that kernel's launches inside the timed region), "cpu_baseline" (the
+CPU oracle oracle/ref_cpu.py timed on this box's host cores on a bounded sample; rank 0, N=1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+NUM_POINT, NUM_CLASS = 1024, 40
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+DOMINANT = os.environ.get("MPA_BENCH_KERNEL", "mpa_diffattn_fwd_f32")
+
+
+def synthetic_batch(B, seed, device):
+    """uniform(-1,1) clouds, centred and scaled into the unit sphere; random labels."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(B, NUM_POINT, 3, generator=g) * 2 - 1
+    x = x - x.mean(1, keepdim=True)
+    x = x / x.norm(dim=-1).max(dim=1)[0].view(B, 1, 1)
+    y = torch.randint(0, NUM_CLASS, (B,), generator=g)
+    return x.transpose(1, 2).contiguous().to(device), y.to(device)
+
+
+def host_cores():
+    """CPU cores this process may actually use: affinity mask, capped by the cgroup CPU quota
+    (os.cpu_count() reports the whole host and oversubscribes a container badly)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            quota, period = open(path).read().split()[:2]
+            if quota != "max":
+                n = min(n, max(1, int(float(quota) / float(period))))
+        except (OSError, ValueError):
+            pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            n = min(n, max(1, q // per))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def log(msg):
+    print("[bench] " + msg, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(batch, steps=3):
+    """The oracle's plain-PyTorch restatement of the reference path, fwd+bwd+Adam on host cores."""
+    from oracle import ref_cpu as R
+    threads = int(os.environ.get("MPA_CPU_THREADS", host_cores()))
+    log("cpu baseline on %d threads (os.cpu_count()=%s)" % (threads, os.cpu_count()))
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    args = argparse.Namespace(num_point=NUM_POINT, return_dist=True, cuda_ops=False, num_class=NUM_CLASS)
+    model = R.ClsModel(args).train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    x, y = synthetic_batch(batch, 1234, "cpu")
+    times = []
+    for i in range(steps + 1):
+        t0 = time.perf_counter()
+        opt.zero_grad(set_to_none=True)
+        loss = R.smooth_cls_loss(model(x), y)
+        loss.backward()
+        opt.step()
+        times.append(time.perf_counter() - t0)
+        log("cpu baseline step %d: %.2f s" % (i, times[-1]))
+    times = sorted(times[1:])
+    med = times[len(times) // 2]
+    return {"value": batch / med, "unit": "point-clouds/s", "cores": threads, "kind": "port",
+            "sample": "oracle/ref_cpu.py ClsModel fwd+bwd+Adam, batch %d x %d pts, 1 warm-up + %d timed steps, median"
+                      % (batch, NUM_POINT, steps)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="clouds per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    import mpa_amd  # noqa: F401
+    from mpa_amd import ops
+    from mpa_amd import distributed as mdist
+    from mpa_amd.models.repsurf.repsurf_ssg_umb import Model, SmoothClsLoss
+
+    if world > 1:
+        mdist.init_process_group()
+    torch.manual_seed(0)
+    args = argparse.Namespace(num_point=NUM_POINT, return_dist=True, cuda_ops=True, num_class=NUM_CLASS)
+    model = Model(args).to(dev).train()
+    reducer = mdist.GradReducer(model) if world > 1 else None
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    crit = SmoothClsLoss()
+    x, y = synthetic_batch(a.batch, 1234 + rank, dev)
+
+    def step():
+        if reducer is not None:
+            reducer.zero_grad()
+        else:
+            opt.zero_grad(set_to_none=True)
+        loss = crit(model(x), y)
+        loss.backward()
+        if reducer is not None:
+            reducer.all_reduce()
+        opt.step()
+        return loss
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    log("rank %d: warm-up done" % rank)
+    ops.enable_kernel_timing([DOMINANT])
+    mdist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    mdist.barrier()
+    elapsed = time.perf_counter() - t0
+    kt = ops.kernel_timing_results().get(DOMINANT)
+    ops.disable_kernel_timing()
+    elapsed = mdist.max_over_ranks(elapsed, dev)
+    log("rank %d: %d steps in %.3f s" % (rank, a.steps, elapsed))
+    assert torch.isfinite(loss).item(), "loss is not finite"
+
+    if rank == 0:
+        clouds = a.batch * world * a.steps
+        roof = None
+        if kt and kt["launches"]:
+            sec = kt["ms"] / 1e3
+            ach = kt["algo_bytes"] / sec / 1e9
+            roof = {"kernel": DOMINANT, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "traffic": None, "launches": kt["launches"],
+                    "avg_launch_us": kt["ms"] * 1e3 / kt["launches"],
+                    "algo_bytes_per_launch": kt["algo_bytes"] / kt["launches"]}
+        line = {
+            "metric": "point-clouds/sec fwd+bwd, ModelNet40 1024pt cls", "value": clouds / elapsed,
+            "unit": "point-clouds/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "ModelNet40-shaped classification, 1024 points, batch %d per GPU, fp32, "
+                                   "fwd+loss+bwd+Adam (BASELINE configs[1])" % a.batch,
+                       "points": NUM_POINT, "batch_per_gpu": a.batch, "global_batch": a.batch * world,
+                       "parallelism": "dp%d" % world},
+            "roofline": roof,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(a.batch)
+        print(json.dumps(line), flush=True)
+    mdist.shutdown()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,135 @@
+/*
+ * mpa_hip.h -- C ABI of libmpa_hip.so: the MI355X (gfx950) implementation of the
+ * reference's Markov set-abstraction hot path.
+ *
+ * The reference (ssr0512/Markov-Process-Analysis-on-Point-Cloud) has no FFI: its boundary is
+ * the Python function / nn.Module API of modules/ (SURVEY.md section 8b).  Each entry point
+ * below replaces the device work of one of those functions; the Python mirror in
+ * markov-process-analysis-on-point-cloud_amd/modules/ keeps the reference names and signatures and calls
+ * these through ctypes.  Paths below are relative to
+ * Markov_Process_Analysis_on_Point_Cloud/ in the reference tree.
+ *
+ * Conventions (all entry points):
+ *   - plain device pointers + sizes; no torch types; no allocation, no ownership transfer,
+ *     no global state; re-entrant; asynchronous on the caller's `stream` (a hipStream_t
+ *     passed as void*), never synchronises the device;
+ *   - tensors are dense row-major, channel-last [B, N, C] float32; indices are int64
+ *     (the reference uses torch.long everywhere);
+ *   - return 0 on success, a negative MPA_E* code on a rejected argument, or
+ *     MPA_EHIP when the launch itself failed (hipGetLastError is consumed).
+ */
+#ifndef MPA_HIP_H
+#define MPA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPA_OK 0
+#define MPA_EINVAL (-1)   /* bad size / null pointer */
+#define MPA_EUNSUPPORTED (-2) /* shape outside what the kernels are built for */
+#define MPA_EHIP (-3)     /* HIP launch error */
+
+int mpa_version(void);
+const char *mpa_error_string(int code);
+/* the hipError_t (and its text) behind the calling thread's most recent MPA_EHIP */
+int mpa_last_hip_error(void);
+const char *mpa_last_hip_error_string(void);
+
+/* ---- farthest_point_sample: modules/pointnet2_utils.py:84-109 (== repsurface_utils.py:150-172)
+ * xyz [B,N,3]; start_idx [B] is the first sample of every cloud (the reference draws it with
+ * torch.randint on the CPU generator, :96 -- the host wrapper does the same and passes it in).
+ * out_idx [B,S] int64; out_xyz [B,S,3] (optional, may be NULL) receives xyz[out_idx], i.e.
+ * the index_points() call that follows every FPS in the models (repsurface_utils.py:583).
+ * Distances follow the reference's rounding exactly (no FMA contraction), ties -> first max. */
+int mpa_fps_f32(const float *xyz, int B, int N, int S, const int64_t *start_idx,
+                int64_t *out_idx, float *out_xyz, void *stream);
+
+/* ---- square_distance: modules/pointnet2_utils.py:190-209.  src [B,S,C], dst [B,N,C] -> out [B,S,N];
+ * bit-exact with the reference CPU result (FMA chain dot, separately rounded norms). */
+int mpa_square_distance_f32(const float *src, const float *dst, int B, int S, int N, int C,
+                            float *out, void *stream);
+
+/* ---- knn_point: modules/pointnet2_utils.py:211-222.  base = `xyz` [B,N,C], query = `new_xyz`
+ * [B,S,C]; K nearest base rows of every query, ascending by (distance, index); the [B,S,N]
+ * matrix is never materialised.  out_dist [B,S,K] (may be NULL), out_idx [B,S,K].
+ * C in {1..8, 16, 32, 64, 128, 256, 512}; K <= 32; K <= N. */
+int mpa_knn_f32(const float *base, const float *query, int B, int N, int S, int C, int K,
+                float *out_dist, int64_t *out_idx, void *stream);
+
+/* ---- query_ball_point: modules/pointnet2_utils.py:112-134.  First `nsample` base indices with
+ * not (d > radius2), padded with the first hit; a row without hits is filled with N. */
+int mpa_ball_query_f32(const float *base, const float *query, int B, int N, int S, int C,
+                       float radius2, int nsample, int64_t *out_idx, void *stream);
+
+/* ---- index_points: modules/pointnet2_utils.py:64-81.  points [B,N,C], idx [B,M] (M = S or S*K)
+ * -> out [B,M,C].  Backward scatter-adds grad_out rows into grad_points (which the caller
+ * has zeroed); duplicate indices are summed with float atomics. */
+int mpa_gather_fwd_f32(const float *points, const int64_t *idx, int B, int N, int M, int C,
+                       float *out, void *stream);
+int mpa_gather_bwd_f32(const float *grad_out, const int64_t *idx, int B, int N, int M, int C,
+                       float *grad_points, void *stream);
+
+/* ---- LocalTrans, feature branch: the difference-wise attention core,
+ * modules/pointnet2_utils.py:548-569 (== repsurface_utils.py:515-535).
+ * q [B,S,C]; k and v are row views with leading dimension ldkv floats (k, v = two column
+ * blocks of one projected [B,N,ldkv] tensor, or separate tensors with ldkv = C);
+ * idx [B,S,K] neighbours into the N base rows.  Per (b,s,c):
+ *   e_j = (q - k[idx_j]) / sqrt(C);  a = softmax_j(e);  w_j = a_j - sum_j a_j;
+ *   ctx = max_j w_j * v[idx_j]
+ * ctx [B,S,C]; argk [B,S,C] uint8 receives the arg-max j (saved for backward). K <= 16. */
+int mpa_diffattn_fwd_f32(const float *q, const float *k, const float *v, int ldkv,
+                         const int64_t *idx, int B, int N, int S, int K, int C,
+                         float *ctx, uint8_t *argk, void *stream);
+/* backward (closed form): recomputes the softmax; grad_q [B,S,C] is
+ * written; grad_k / grad_v (leading dimension ldg, zeroed by the caller) are accumulated
+ * through idx with float atomics. */
+int mpa_diffattn_bwd_f32(const float *q, const float *k, const float *v, int ldkv,
+                         const int64_t *idx, const uint8_t *argk, const float *grad_ctx,
+                         int B, int N, int S, int K, int C,
+                         float *grad_q, float *grad_k, float *grad_v, int ldg, void *stream);
+
+/* ---- LocalTrans, xyz branch: modules/pointnet2_utils.py:518-544.  k and v are Linear(3->C)
+ * applied to neighbour offsets, so the whole branch is one kernel on raw coordinates:
+ *   q = Wq c + bq;  k_j = Wk (x[idx_j] - c) + bk;  v_j = Wv (x[idx_j] - c) + bv;  then as above.
+ * xyz [B,N,3] base coordinates, center [B,S,3]; W* [C,3] row-major (nn.Linear.weight), b* [C]. */
+int mpa_diffattn_xyz_fwd_f32(const float *xyz, const float *center, const int64_t *idx,
+                             const float *Wq, const float *bq, const float *Wk, const float *bk,
+                             const float *Wv, const float *bv,
+                             int B, int N, int S, int K, int C,
+                             float *ctx, uint8_t *argk, void *stream);
+/* backward: accumulates (atomics; caller zeroes) gWq,gWk,gWv [C,3] and gbq,gbk,gbv [C].
+ * Coordinates are inputs of the network and receive no gradient. */
+int mpa_diffattn_xyz_bwd_f32(const float *xyz, const float *center, const int64_t *idx,
+                             const float *Wq, const float *bq, const float *Wk, const float *bk,
+                             const float *Wv, const float *bv, const uint8_t *argk,
+                             const float *grad_ctx, int B, int N, int S, int K, int C,
+                             float *gWq, float *gbq, float *gWk, float *gbk, float *gWv, float *gbv,
+                             void *stream);
+
+/* ---- upsample: the decoder's coarse->fine transition, modules/pointnet2_utils.py:13-50.
+ * points [B,S,C], knn_idx [B,S,K] with values < Nf (= S*scale_ratio).  out [B,Nf,C] is the
+ * mean, over the coarse rows s that list fine point n, of points[s]; the divisor counts only
+ * contributors whose channel-0 value is non-zero (0 -> 1), uncovered fine points stay 0
+ * (the reference's quirks, :44-46).  The dense [B,S,Nf,C] tensor is never formed.
+ * cnt [B,Nf] float (output, kept for backward).  out and cnt are zeroed by the callee. */
+int mpa_upsample_mean_fwd_f32(const float *points, const int64_t *knn_idx, int B, int S, int K,
+                              int Nf, int C, float *out, float *cnt, void *stream);
+int mpa_upsample_mean_bwd_f32(const float *grad_out, const int64_t *knn_idx, const float *cnt,
+                              int B, int S, int K, int Nf, int C, float *grad_points,
+                              void *stream);
+
+/* ---- PointNetFeaturePropagation interpolation: modules/pointnet2_utils.py:899-906.
+ * three_nn = mpa_knn_f32 with K = 3 (query = xyz1, base = xyz2).
+ * out[b,n,:] = sum_j w_j * points2[b, idx[b,n,j], :],  w_j = (1/(d_j+1e-8)) / sum_j (1/(d_j+1e-8)). */
+int mpa_three_interp_fwd_f32(const float *points2, const int64_t *idx, const float *dist,
+                             int B, int Nq, int Nb, int C, float *out, void *stream);
+int mpa_three_interp_bwd_f32(const float *grad_out, const int64_t *idx, const float *dist,
+                             int B, int Nq, int Nb, int C, float *grad_points2, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPA_HIP_H */

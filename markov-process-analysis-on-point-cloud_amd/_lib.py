@@ -1,0 +1,65 @@
+"""ctypes binding of libmpa_hip.so (C ABI declared in include/mpa_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing this module raises
+at import time, and every op raises on non-CUDA tensors.
+"""
+import ctypes
+import os
+
+# torch must be loaded BEFORE libmpa_hip.so: the wheel bundles its own libamdhip64.so.7 and the
+# library's DT_NEEDED entry has the same soname, so with torch first the dynamic loader binds
+# both to ONE HIP runtime (shared device context, streams and allocations).  Loaded the other
+# way round the process ends up with two runtimes and launches fail with hipErrorNoDevice.
+import torch  # noqa: F401  (ordering, see above)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmpa_hip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "libmpa_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+        "(or `make -C markov-process-analysis-on-point-cloud_amd/csrc`). There is no CPU fallback." % LIB_PATH)
+
+lib = ctypes.CDLL(LIB_PATH)
+
+_vp, _i, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+
+# name -> argtypes (restype is int unless noted); order must match include/mpa_hip.h
+SIGNATURES = {
+    "mpa_fps_f32": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "mpa_square_distance_f32": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
+    "mpa_knn_f32": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp],
+    "mpa_ball_query_f32": [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp],
+    "mpa_gather_fwd_f32": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
+    "mpa_gather_bwd_f32": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
+    "mpa_diffattn_fwd_f32": [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp],
+    "mpa_diffattn_bwd_f32": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp],
+    "mpa_diffattn_xyz_fwd_f32": [_vp] * 9 + [_i] * 5 + [_vp, _vp, _vp],
+    "mpa_diffattn_xyz_bwd_f32": [_vp] * 11 + [_i] * 5 + [_vp] * 6 + [_vp],
+    "mpa_upsample_mean_fwd_f32": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp],
+    "mpa_upsample_mean_bwd_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
+    "mpa_three_interp_fwd_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
+    "mpa_three_interp_bwd_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
+}
+
+for _name, _args in SIGNATURES.items():
+    _fn = getattr(lib, _name)
+    _fn.argtypes = _args
+    _fn.restype = ctypes.c_int
+lib.mpa_version.restype = ctypes.c_int
+lib.mpa_error_string.restype = ctypes.c_char_p
+lib.mpa_error_string.argtypes = [ctypes.c_int]
+lib.mpa_last_hip_error.restype = ctypes.c_int
+lib.mpa_last_hip_error_string.restype = ctypes.c_char_p
+
+
+class MpaError(RuntimeError):
+    pass
+
+
+def check(rc, what):
+    if rc != 0:
+        detail = ""
+        if rc == -3:
+            detail = " [hipError %d: %s]" % (lib.mpa_last_hip_error(), lib.mpa_last_hip_error_string().decode())
+        raise MpaError("%s failed: %s (code %d)%s" % (what, lib.mpa_error_string(rc).decode(), rc, detail))

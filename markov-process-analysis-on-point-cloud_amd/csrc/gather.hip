@@ -1,0 +1,243 @@
+// Row gathers / scatters for gfx950: index_points (reference modules/pointnet2_utils.py:64-81),
+// upsample (:13-50) and the 3-NN interpolation of PointNetFeaturePropagation (:899-906).
+// All are HBM/L2-bound row moves: one lane moves a float4 of a C-float row, so a wave covers
+// 1 KiB of contiguous row bytes per instruction; scatters use no-return float atomics on whole
+// rows (the shape that runs at the full atomic rate, MI355X guide "Global float atomics").
+#include "mpa_common.h"
+
+namespace {
+
+constexpr int TPB = 256;
+
+// out[b,m,:] = points[b, idx[b,m], :]
+template <typename V>
+__global__ void gather_fwd_kernel(const float *__restrict__ points, const int64_t *__restrict__ idx, int N, int M,
+                                  int CV, long long total, float *__restrict__ out)
+{
+    // total = B*M*CV vector elements; CV = C / lanes-per-vector
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        long long row = i / CV;
+        int c = (int)(i - row * CV);
+        int b = (int)(row / M);
+        long long src = (long long)b * N + idx[row];
+        reinterpret_cast<V *>(out)[i] = reinterpret_cast<const V *>(points)[src * CV + c];
+    }
+}
+
+// grad_points[b, idx[b,m], :] += grad_out[b,m,:]
+__global__ void gather_bwd_kernel(const float *__restrict__ grad_out, const int64_t *__restrict__ idx, int N, int M,
+                                  int C, long long total, float *__restrict__ grad_points)
+{
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        long long row = i / C;
+        int c = (int)(i - row * C);
+        int b = (int)(row / M);
+        long long dst = (long long)b * N + idx[row];
+        atomicAdd(grad_points + dst * C + c, grad_out[i]);
+    }
+}
+
+// upsample forward, scatter phase: every coarse row s adds itself to the fine rows it lists
+// (once per distinct fine index: scatter_ semantics) and bumps their divisor if p[s][0] != 0.
+__global__ void upsample_scatter_kernel(const float *__restrict__ points, const int64_t *__restrict__ knn, int S,
+                                        int K, int Nf, int C, long long total, float *__restrict__ out,
+                                        float *__restrict__ cnt)
+{
+    // one thread per (b, s, k, c)
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        long long e = i / C;            // (b*S + s)*K + k
+        int c = (int)(i - e * C);
+        long long bs = e / K;
+        int k = (int)(e - bs * K);
+        int b = (int)(bs / S);
+        const int64_t *row = knn + bs * K;
+        int64_t n = row[k];
+        bool dup = false;
+        for (int j = 0; j < k; ++j) dup |= (row[j] == n);
+        if (dup) continue;
+        float p = points[bs * C + c];
+        long long dst = (long long)b * Nf + n;
+        atomicAdd(out + dst * C + c, p);
+        if (c == 0 && p != 0.0f) atomicAdd(cnt + dst, 1.0f);
+    }
+}
+
+__global__ void upsample_divide_kernel(float *__restrict__ out, const float *__restrict__ cnt, int C, long long total)
+{
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        float n = cnt[i / C];
+        n = n == 0.0f ? 1.0f : n;
+        out[i] = out[i] / n;
+    }
+}
+
+// grad_points[b,s,:] = sum over distinct n in knn[b,s,:] of grad_out[b,n,:] / max(cnt[b,n],1)
+__global__ void upsample_bwd_kernel(const float *__restrict__ grad_out, const int64_t *__restrict__ knn,
+                                    const float *__restrict__ cnt, int S, int K, int Nf, int C, long long total,
+                                    float *__restrict__ grad_points)
+{
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        long long bs = i / C;
+        int c = (int)(i - bs * C);
+        int b = (int)(bs / S);
+        const int64_t *row = knn + bs * K;
+        float acc = 0.f;
+        for (int k = 0; k < K; ++k) {
+            int64_t n = row[k];
+            bool dup = false;
+            for (int j = 0; j < k; ++j) dup |= (row[j] == n);
+            if (dup) continue;
+            long long src = (long long)b * Nf + n;
+            float d = cnt[src];
+            d = d == 0.0f ? 1.0f : d;
+            acc += grad_out[src * C + c] / d;
+        }
+        grad_points[i] = acc;
+    }
+}
+
+__device__ __forceinline__ void interp_weights(const float *d, float w[3])
+{
+    float r0 = 1.0f / (d[0] + 1e-8f), r1 = 1.0f / (d[1] + 1e-8f), r2 = 1.0f / (d[2] + 1e-8f);
+    float nrm = (r0 + r1) + r2;
+    w[0] = r0 / nrm; w[1] = r1 / nrm; w[2] = r2 / nrm;
+}
+
+__global__ void interp_fwd_kernel(const float *__restrict__ points2, const int64_t *__restrict__ idx,
+                                  const float *__restrict__ dist, int Nq, int Nb, int C, long long total,
+                                  float *__restrict__ out)
+{
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        long long row = i / C;
+        int c = (int)(i - row * C);
+        int b = (int)(row / Nq);
+        float w[3];
+        interp_weights(dist + row * 3, w);
+        const int64_t *id = idx + row * 3;
+        const float *p = points2 + (long long)b * Nb * C + c;
+        float acc = p[id[0] * C] * w[0];
+        acc += p[id[1] * C] * w[1];
+        acc += p[id[2] * C] * w[2];
+        out[i] = acc;
+    }
+}
+
+__global__ void interp_bwd_kernel(const float *__restrict__ grad_out, const int64_t *__restrict__ idx,
+                                  const float *__restrict__ dist, int Nq, int Nb, int C, long long total,
+                                  float *__restrict__ grad_points2)
+{
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        long long row = i / C;
+        int c = (int)(i - row * C);
+        int b = (int)(row / Nq);
+        float w[3];
+        interp_weights(dist + row * 3, w);
+        const int64_t *id = idx + row * 3;
+        float *p = grad_points2 + (long long)b * Nb * C + c;
+        float g = grad_out[i];
+        atomicAdd(p + id[0] * C, g * w[0]);
+        atomicAdd(p + id[1] * C, g * w[1]);
+        atomicAdd(p + id[2] * C, g * w[2]);
+    }
+}
+
+inline int grid_for(long long total)
+{
+    long long g = (total + TPB - 1) / TPB;
+    return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
+}
+
+}  // namespace
+
+extern "C" int mpa_gather_fwd_f32(const float *points, const int64_t *idx, int B, int N, int M, int C, float *out,
+                                  void *stream)
+{
+    MPA_CLEAR_ERROR();
+    if (!points || !idx || !out || B <= 0 || N <= 0 || M <= 0 || C <= 0) return MPA_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    bool al16 = (((uintptr_t)points | (uintptr_t)out) & 15) == 0;
+    if ((C & 3) == 0 && al16) {
+        long long total = (long long)B * M * (C / 4);
+        hipLaunchKernelGGL(gather_fwd_kernel<float4>, dim3(grid_for(total)), dim3(TPB), 0, st, points, idx, N, M,
+                           C / 4, total, out);
+    } else {
+        long long total = (long long)B * M * C;
+        hipLaunchKernelGGL(gather_fwd_kernel<float>, dim3(grid_for(total)), dim3(TPB), 0, st, points, idx, N, M, C,
+                           total, out);
+    }
+    MPA_LAUNCH_CHECK();
+    return MPA_OK;
+}
+
+extern "C" int mpa_gather_bwd_f32(const float *grad_out, const int64_t *idx, int B, int N, int M, int C,
+                                  float *grad_points, void *stream)
+{
+    MPA_CLEAR_ERROR();
+    if (!grad_out || !idx || !grad_points || B <= 0 || N <= 0 || M <= 0 || C <= 0) return MPA_EINVAL;
+    long long total = (long long)B * M * C;
+    hipLaunchKernelGGL(gather_bwd_kernel, dim3(grid_for(total)), dim3(TPB), 0, (hipStream_t)stream, grad_out, idx, N,
+                       M, C, total, grad_points);
+    MPA_LAUNCH_CHECK();
+    return MPA_OK;
+}
+
+extern "C" int mpa_upsample_mean_fwd_f32(const float *points, const int64_t *knn_idx, int B, int S, int K, int Nf,
+                                         int C, float *out, float *cnt, void *stream)
+{
+    MPA_CLEAR_ERROR();
+    if (!points || !knn_idx || !out || !cnt || B <= 0 || S <= 0 || K <= 0 || Nf <= 0 || C <= 0) return MPA_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * Nf * C, st) != hipSuccess) return MPA_EHIP;
+    if (hipMemsetAsync(cnt, 0, sizeof(float) * (size_t)B * Nf, st) != hipSuccess) return MPA_EHIP;
+    long long total = (long long)B * S * K * C;
+    hipLaunchKernelGGL(upsample_scatter_kernel, dim3(grid_for(total)), dim3(TPB), 0, st, points, knn_idx, S, K, Nf, C,
+                       total, out, cnt);
+    long long tot2 = (long long)B * Nf * C;
+    hipLaunchKernelGGL(upsample_divide_kernel, dim3(grid_for(tot2)), dim3(TPB), 0, st, out, cnt, C, tot2);
+    MPA_LAUNCH_CHECK();
+    return MPA_OK;
+}
+
+extern "C" int mpa_upsample_mean_bwd_f32(const float *grad_out, const int64_t *knn_idx, const float *cnt, int B,
+                                         int S, int K, int Nf, int C, float *grad_points, void *stream)
+{
+    MPA_CLEAR_ERROR();
+    if (!grad_out || !knn_idx || !cnt || !grad_points || B <= 0 || S <= 0 || K <= 0 || Nf <= 0 || C <= 0)
+        return MPA_EINVAL;
+    long long total = (long long)B * S * C;
+    hipLaunchKernelGGL(upsample_bwd_kernel, dim3(grid_for(total)), dim3(TPB), 0, (hipStream_t)stream, grad_out,
+                       knn_idx, cnt, S, K, Nf, C, total, grad_points);
+    MPA_LAUNCH_CHECK();
+    return MPA_OK;
+}
+
+extern "C" int mpa_three_interp_fwd_f32(const float *points2, const int64_t *idx, const float *dist, int B, int Nq,
+                                        int Nb, int C, float *out, void *stream)
+{
+    MPA_CLEAR_ERROR();
+    if (!points2 || !idx || !dist || !out || B <= 0 || Nq <= 0 || Nb <= 0 || C <= 0) return MPA_EINVAL;
+    long long total = (long long)B * Nq * C;
+    hipLaunchKernelGGL(interp_fwd_kernel, dim3(grid_for(total)), dim3(TPB), 0, (hipStream_t)stream, points2, idx, dist,
+                       Nq, Nb, C, total, out);
+    MPA_LAUNCH_CHECK();
+    return MPA_OK;
+}
+
+extern "C" int mpa_three_interp_bwd_f32(const float *grad_out, const int64_t *idx, const float *dist, int B, int Nq,
+                                        int Nb, int C, float *grad_points2, void *stream)
+{
+    MPA_CLEAR_ERROR();
+    if (!grad_out || !idx || !dist || !grad_points2 || B <= 0 || Nq <= 0 || Nb <= 0 || C <= 0) return MPA_EINVAL;
+    long long total = (long long)B * Nq * C;
+    hipLaunchKernelGGL(interp_bwd_kernel, dim3(grid_for(total)), dim3(TPB), 0, (hipStream_t)stream, grad_out, idx,
+                       dist, Nq, Nb, C, total, grad_points2);
+    MPA_LAUNCH_CHECK();
+    return MPA_OK;
+}

@@ -1,0 +1,161 @@
+"""One-process-per-GPU data parallelism for the Markov set-abstraction path.
+
+The path shards by batch: FPS, kNN, grouping, attention and upsample are all per-cloud, so each
+rank owns B/world clouds and there is NO data-path collective.  The only exchange is one
+all-reduce (mean) of the gradients per step, over RCCL (`backend="nccl"` on ROCm) on xGMI.
+The reference has no distributed code at all (single GPU selected by a hard-coded env var,
+tool/train_cls_scanobjectnn.py:135); this is the "scripts/ train loop DDP init" named by
+BASELINE.json's north_star.
+
+Design for xGMI (point-to-point links, per-link-bound rings): gradients live in a few large flat
+buckets (default 16 MiB; cls has 25.7 MB of live gradients -> 2 buckets), parameters' .grad are
+views into them, and each bucket's all-reduce is launched from a post-accumulate hook as soon as
+its last gradient lands, overlapping the rest of backward.  Parameters that never receive a
+gradient (2.1 M in cls: normal_Trans, fc1, start, final, every norm1) are left out of the
+buckets but stay in the state dict.
+
+BatchNorm statistics stay per-rank (as plain DDP does); see DESIGN.md for the caveat.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def is_dist():
+    return dist.is_available() and dist.is_initialized()
+
+
+def init_process_group(backend=None):
+    """Reads RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT from the environment (torchrun)."""
+    if is_dist():
+        return
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    kw = {}
+    if backend == "nccl":
+        kw["device_id"] = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    dist.init_process_group(backend=backend, **kw)
+
+
+def shutdown():
+    if is_dist():
+        dist.destroy_process_group()
+
+
+def world_size():
+    return dist.get_world_size() if is_dist() else 1
+
+
+def rank():
+    return dist.get_rank() if is_dist() else 0
+
+
+def barrier():
+    if is_dist():
+        dist.barrier()
+
+
+def max_over_ranks(value, device="cpu"):
+    if not is_dist():
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def shard_batch(n_items, r=None, w=None):
+    """Contiguous [start, stop) slice of a global batch owned by rank r of w."""
+    r = rank() if r is None else r
+    w = world_size() if w is None else w
+    base, rem = divmod(n_items, w)
+    start = r * base + min(r, rem)
+    return start, start + base + (1 if r < rem else 0)
+
+
+class GradReducer:
+    """Bucketed, backward-overlapped gradient all-reduce (mean) over the default process group.
+
+    Usage per step:   reducer.zero_grad(); loss.backward(); reducer.all_reduce(); opt.step()
+    The first backward discovers which parameters receive gradients; from then on their .grad
+    tensors are views into flat buckets and reductions start from autograd hooks."""
+
+    def __init__(self, module, bucket_bytes=16 << 20):
+        self.params = [p for p in module.parameters() if p.requires_grad]
+        self.bucket_bytes = bucket_bytes
+        self.buckets = None          # list of dicts: flat, params, pending, handle
+        self._where = {}
+        self._handles = []
+
+    # -- bucket construction (after the first backward) --------------------------------------
+    def _build(self):
+        live = [p for p in self.params if p.grad is not None]
+        live.reverse()               # roughly the order gradients become ready
+        self.buckets = []
+        cur, cur_bytes = [], 0
+        for p in live:
+            nbytes = p.numel() * p.element_size()
+            if cur and cur_bytes + nbytes > self.bucket_bytes:
+                self._make_bucket(cur)
+                cur, cur_bytes = [], 0
+            cur.append(p)
+            cur_bytes += nbytes
+        if cur:
+            self._make_bucket(cur)
+        for p in live:
+            p.register_post_accumulate_grad_hook(self._hook)
+
+    def _make_bucket(self, params):
+        total = sum(p.numel() for p in params)
+        flat = torch.zeros(total, dtype=params[0].dtype, device=params[0].device)
+        b = {"flat": flat, "params": params, "pending": len(params), "views": []}
+        off = 0
+        for p in params:
+            v = flat[off:off + p.numel()].view_as(p)
+            v.copy_(p.grad)
+            p.grad = v
+            b["views"].append(v)
+            self._where[p] = b
+            off += p.numel()
+        self.buckets.append(b)
+
+    def _hook(self, p):
+        b = self._where.get(p)
+        if b is None or not is_dist():
+            return
+        b["pending"] -= 1
+        if b["pending"] == 0:
+            self._handles.append(dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, async_op=True))
+
+    # -- per-step API ------------------------------------------------------------------------
+    def zero_grad(self):
+        if self.buckets is None:
+            for p in self.params:
+                p.grad = None
+            return
+        for b in self.buckets:
+            b["flat"].zero_()
+            b["pending"] = len(b["params"])
+            for p, v in zip(b["params"], b["views"]):
+                p.grad = v
+
+    def all_reduce(self):
+        """Completes the step's reduction: gradients become the mean over ranks."""
+        w = world_size()
+        if self.buckets is None:
+            self._build()
+            if is_dist():
+                for b in self.buckets:
+                    dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM)
+        else:
+            for b in self.buckets:      # a bucket whose hook did not fire (unused this step)
+                if b["pending"] != 0 and is_dist():
+                    self._handles.append(dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, async_op=True))
+            for h in self._handles:
+                h.wait()
+            self._handles = []
+        if w > 1:
+            for b in self.buckets:
+                b["flat"].div_(w)

@@ -1,0 +1,46 @@
+"""Classification wiring -- drop-in for the reference's models/repsurf/repsurf_ssg_umb.py:35-70
+(class Model): KeepHighResolutionModule + a three-layer FC head, log-softmax output.
+State-dict keys equal the reference's."""
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ...modules.repsurface_utils import KeepHighResolutionModule, index_points  # noqa: F401
+
+
+class Model(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        self.init_nsample = args.num_point
+        self.return_dist = args.return_dist
+        self.keepHigh = KeepHighResolutionModule(3, 64, 64, 64, 64, cuda=args.cuda_ops)
+        self.fc1 = nn.Linear(1024, 512)
+        self.bn1 = nn.BatchNorm1d(512)
+        self.drop1 = nn.Dropout(0.5)
+        self.fc2 = nn.Linear(512, 256)
+        self.bn2 = nn.BatchNorm1d(256)
+        self.drop2 = nn.Dropout(0.5)
+        self.fc3 = nn.Linear(256, args.num_class)
+        self.lrelu = nn.LeakyReLU(negative_slope=0.2)
+
+    def forward(self, points):
+        center = points[:, :3, :]
+        normal = center                       # as the reference (:59): the normal input is dead
+        x = self.keepHigh(center, normal)
+        x = self.drop1(self.lrelu(self.bn1(self.fc1(x))))
+        x = self.drop2(self.lrelu(self.bn2(self.fc2(x))))
+        return F.log_softmax(self.fc3(x), -1)
+
+
+class SmoothClsLoss(nn.Module):
+    """Label-smoothed NLL on log-probabilities (reference util/utils.py:74-88)."""
+
+    def __init__(self, smoothing_ratio=0.1):
+        super().__init__()
+        self.smoothing_ratio = smoothing_ratio
+
+    def forward(self, pred, target):
+        eps = self.smoothing_ratio
+        n_class = pred.size(1)
+        one_hot = pred.new_zeros(pred.shape).scatter(1, target.view(-1, 1), 1)
+        one_hot = one_hot * (1 - eps) + (1 - one_hot) * eps / (n_class - 1)
+        return -(one_hot * pred).sum(dim=1).mean()

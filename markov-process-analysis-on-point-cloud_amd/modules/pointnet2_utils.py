@@ -1,0 +1,259 @@
+"""Drop-in for the reference's modules/pointnet2_utils.py on MI355X: the same operator names,
+nn.Module classes, constructor signatures and state-dict keys, with the device work done by
+the gfx950 kernels of libmpa_hip.so (see ../ops.py).
+
+Reference locations (Markov_Process_Analysis_on_Point_Cloud/modules/pointnet2_utils.py):
+  upsample:13  index_points:64  farthest_point_sample:84  query_ball_point:112
+  sample_and_group:137  square_distance:190  knn_point:211  Linear:401  LocalMerge:427
+  LocalTrans:479  Fuse:576  KeepHighResolutionModulePartSeg:711  PointNetFeaturePropagation:860
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from ..ops import (farthest_point_sample, index_points, knn_point, query_ball_point, query_knn_point,  # noqa: F401
+                   sample, square_distance, three_interpolate, three_nn, upsample)
+
+
+def sample_and_group(npoint, radius, nsample, xyz, points, returnfps=False):
+    """reference :137-165 -- FPS, ball query, centre-relative grouping."""
+    B, N, C = xyz.shape
+    fps_idx = farthest_point_sample(xyz, npoint)
+    new_xyz = index_points(xyz, fps_idx)
+    idx = query_ball_point(radius, nsample, xyz, new_xyz)
+    grouped_xyz = index_points(xyz, idx)
+    grouped_xyz_norm = grouped_xyz - new_xyz.view(B, npoint, 1, C)
+    if points is not None:
+        new_points = torch.cat([grouped_xyz_norm, index_points(points, idx)], dim=-1)
+    else:
+        new_points = grouped_xyz_norm
+    if returnfps:
+        return new_xyz, new_points, grouped_xyz, fps_idx
+    return new_xyz, new_points
+
+
+class Linear(nn.Module):
+    """The transition / pointwise MLP unit (reference :401-425): nn.Linear, then LayerNorm
+    (`bn=True`, never used by the models) or BatchNorm1d over the B*S rows (`bn=False`), then
+    LeakyReLU(0.2) if `act`.  Input must be [B,S,C]."""
+
+    def __init__(self, in_channels, out_channels, bn=True, act=True):
+        super().__init__()
+        self.act_flag = act
+        self.bn_flag = bn
+        self.linear = nn.Linear(in_channels, out_channels)
+        self.norm1 = nn.LayerNorm(out_channels)
+        self.norm2 = nn.BatchNorm1d(out_channels)
+        self.act = nn.LeakyReLU(negative_slope=0.2)
+
+    def forward(self, input):
+        if input.dim() != 3:
+            raise ValueError("Linear expects a [B,S,C] input (as the reference's BatchNorm1d permute does)")
+        if self.bn_flag:
+            out = self.norm1(self.linear(input))
+            return self.act(out) if self.act_flag else out
+        return ops.linear_bn_act(input, self.linear.weight, self.linear.bias, self.norm2,
+                                 0.2 if self.act_flag else None)
+
+
+class LocalTrans(nn.Module):
+    """Difference-wise attention between a point-set state and its K-neighbourhoods in the
+    previous state (reference :479-574)."""
+
+    def __init__(self, in_c, out_c, patch_num, usetanh=False, residual=False):
+        super().__init__()
+        self.patchNum = patch_num
+        self.residual = residual
+        self.usetanh = usetanh
+        self.out_c = out_c
+        self.q = nn.Linear(in_c, out_c)
+        self.k = nn.Linear(in_c, out_c)
+        self.v = nn.Linear(in_c, out_c)
+        self.conv_res = Linear(in_c, out_c, bn=False)
+        self.ffn = Linear(out_c, out_c, bn=False)
+        self.tanh = nn.Tanh()
+
+    def forward(self, features, idx, pos, FPS_idx=None, xyz=False):
+        if self.usetanh:
+            raise NotImplementedError("usetanh=True is dead code in the reference models (always False)")
+        center = index_points(features, FPS_idx) if FPS_idx is not None else features
+        residual = self.conv_res(center) if self.residual else center
+        if xyz:
+            context = ops.diffattn_xyz(features, center, idx, self.q.weight, self.q.bias, self.k.weight,
+                                       self.k.bias, self.v.weight, self.v.bias)
+        else:
+            q = ops.linear(center, self.q.weight, self.q.bias)
+            kv = ops.linear(features, torch.cat((self.k.weight, self.v.weight), 0),
+                            torch.cat((self.k.bias, self.v.bias), 0))
+            context = ops.diffattn(q, kv, idx)
+        return residual + self.ffn(context)
+
+
+class LocalMerge(nn.Module):
+    """State -> state probability-transition block, part-seg variant (reference :427-477):
+    xyz-space and feature-space neighbourhoods, three attention streams, fc2 over 3*out."""
+
+    def __init__(self, in_channels, out_channels, knn, usetanh=False, residual=False):
+        super().__init__()
+        self.knn = knn
+        self.usetanh = usetanh
+        self.residual = residual
+        self.fc2 = Linear(out_channels * 3, out_channels, bn=False)
+        self.xyz_Trans = LocalTrans(3, out_channels, knn, usetanh=usetanh, residual=True)
+        self.normal_Trans = LocalTrans(10, out_channels, knn, usetanh=usetanh, residual=True)
+        self.feature_Trans1 = LocalTrans(in_channels, out_channels, knn, usetanh=usetanh, residual=residual)
+        self.feature_Trans2 = LocalTrans(in_channels, out_channels, knn, usetanh=usetanh, residual=residual)
+
+    def forward(self, xyz, base_xyz, normal=None, feature=None, FPS_idx=None, xyz_flag=True):
+        dist, idx = knn_point(self.knn, base_xyz, xyz)
+        if feature is None:
+            merge_features = self.xyz_Trans(features=xyz, idx=idx, pos=base_xyz, FPS_idx=FPS_idx, xyz=True)
+        else:
+            fs = feature if FPS_idx is None else index_points(feature, FPS_idx)
+            _, idx_feature = knn_point(self.knn, feature, fs)
+            xyz_f = self.xyz_Trans(features=base_xyz, idx=idx, pos=base_xyz, FPS_idx=FPS_idx, xyz=True)
+            f1 = self.feature_Trans1(features=feature, idx=idx, pos=base_xyz, FPS_idx=FPS_idx)
+            f2 = self.feature_Trans2(features=feature, idx=idx_feature, pos=base_xyz, FPS_idx=FPS_idx)
+            merge_features = self.fc2(torch.cat((xyz_f, f1, f2), dim=2))
+        if FPS_idx is not None:
+            normal = index_points(normal, FPS_idx)
+        return merge_features, normal, idx, dist
+
+
+def _compose(*maps):
+    """FPS_a[FPS_b[...]]: index of a coarser state's points in a finer state."""
+    out = maps[-1]
+    for m in reversed(maps[:-1]):
+        out = torch.gather(m, 1, out)
+    return out
+
+
+class Fuse(nn.Module):
+    """Cross-state fusion (reference :576-709): bring every other state's features to the target
+    state (composed FPS gathers downwards, `upsample` upwards), one Linear each, sum, Linear,
+    residual.  The reference selects the target by the literal counts 128..2048; here the target
+    is the state whose size equals `num_point`, which is identical at N=2048 and also works for
+    other cloud sizes."""
+
+    def __init__(self, c0, c1, c2, c3, c4):
+        super().__init__()
+        self.knn = 8
+        c = (c0, c1, c2, c3, c4)
+        for dst in (4, 3, 2, 1, 0):
+            for src in range(5):
+                if src != dst:
+                    setattr(self, "conv%d%d" % (src, dst), Linear(c[src], c[dst], bn=False))
+            setattr(self, "conv%d" % dst, Linear(c[dst], c[dst], bn=False))
+
+    def forward(self, num_point, f0=None, f1=None, f2=None, f3=None, f4=None, FPS_0=None, FPS_1=None, FPS_2=None,
+                FPS_3=None, knn_0=None, knn_1=None, knn_2=None, knn_3=None, knn_4=None, xyz0=None, xyz1=None,
+                xyz2=None, xyz3=None, xyz4=None):
+        f = [f0, f1, f2, f3, f4]
+        fps = [FPS_0, FPS_1, FPS_2, FPS_3]
+        knn = [knn_0, knn_1, knn_2, knn_3, knn_4]
+        xyz = [xyz0, xyz1, xyz2, xyz3, xyz4]
+        dst = [t.shape[1] for t in f].index(num_point)
+        acc = f[dst]
+        for src in range(5):
+            if src == dst:
+                continue
+            conv = getattr(self, "conv%d%d" % (src, dst))
+            if src < dst:      # finer -> coarser: gather through the composed FPS maps
+                t = index_points(f[src], _compose(*fps[src:dst]))
+            elif src == dst + 1:   # adjacent coarser state: reuse the encoder's kNN
+                t = upsample(f[src], knn[src])
+            else:              # non-adjacent: fresh xyz kNN of the coarse state in the target state
+                ratio = f[dst].shape[1] // f[src].shape[1]
+                t = upsample(f[src], knn_point(self.knn, xyz[dst], xyz[src])[1], scale_ratio=ratio)
+            acc = acc + conv(t)
+        f[dst] = getattr(self, "conv%d" % dst)(acc) + f[dst]
+        return tuple(f)
+
+
+class KeepHighResolutionModulePartSeg(nn.Module):
+    """Part-seg encoder-decoder wiring (reference :711-858)."""
+
+    def __init__(self, data_C, b1_C, b2_C, b3_C, b4_C, cuda=False):
+        super().__init__()
+        self.neighbour = 16
+        self.cuda_ops = cuda   # the reference stores this as `self.cuda`, shadowing nn.Module.cuda
+        self.start = Linear(3, 32, bn=False)
+        self.la0 = LocalMerge(32, 64, 8, usetanh=False, residual=True)
+        self.la1 = LocalMerge(64, 64, 8, usetanh=False, residual=False)
+        self.la2 = LocalMerge(64, 64, 8, usetanh=False, residual=False)
+        self.la3 = LocalMerge(64, 128, 8, usetanh=False, residual=True)
+        self.la4 = LocalMerge(128, 256, 8, usetanh=False, residual=True)
+        self.la4_up = LocalMerge(128, 128, 8, usetanh=False, residual=False)
+        self.la3_up = LocalMerge(64, 64, 8, usetanh=False, residual=False)
+        self.la2_up = LocalMerge(64, 64, 8, usetanh=False, residual=False)
+        self.la1_up = LocalMerge(64, 64, 8, usetanh=False, residual=False)
+        self.up_conv4 = Linear(256, 128, bn=False)
+        self.up_conv3 = Linear(128, 64, bn=False)
+        self.up_conv2 = Linear(64, 64, bn=False)
+        self.up_conv1 = Linear(64, 64, bn=False)
+        self.mlp = Linear(256, 256, bn=False)
+        self.conv5 = Linear(64, 256, bn=False)
+        self.conv6 = Linear(64, 128, bn=False)
+        self.conv7 = Linear(16, 64, bn=False)
+        self.conv8 = Linear(64, 256, bn=False)
+        self.fuse1 = Fuse(64, 64, 64, 128, 256)
+        self.fuse2 = Fuse(64, 64, 64, 128, 256)
+        self.fuse3 = Fuse(64, 64, 64, 128, 256)
+        self.fuse4 = Fuse(64, 64, 64, 128, 256)
+        self.fuse5 = Fuse(64, 64, 64, 128, 256)
+        self.lrelu = nn.LeakyReLU(negative_slope=0.2)
+
+    def forward(self, xyz, normal, label):
+        x0 = xyz.permute(0, 2, 1).contiguous()
+        nrm = normal.permute(0, 2, 1).contiguous()
+        N = x0.shape[1]
+        # encoder: four FPS halvings, one LocalMerge per state
+        e0, n0, k0, d0_ = self.la0(xyz=x0, base_xyz=x0, normal=nrm, xyz_flag=True)
+        p0, x1 = farthest_point_sample(x0, N // 2, return_xyz=True)
+        e1, n1, k1, _ = self.la1(xyz=x1, base_xyz=x0, normal=n0, feature=e0, FPS_idx=p0, xyz_flag=True)
+        p1, x2 = farthest_point_sample(x1, N // 4, return_xyz=True)
+        e2, n2, k2, _ = self.la2(xyz=x2, base_xyz=x1, normal=n1, feature=e1, FPS_idx=p1, xyz_flag=False)
+        p2, x3 = farthest_point_sample(x2, N // 8, return_xyz=True)
+        e3, n3, k3, _ = self.la3(xyz=x3, base_xyz=x2, normal=n2, feature=e2, FPS_idx=p2, xyz_flag=True)
+        p3, x4 = farthest_point_sample(x3, N // 16, return_xyz=True)
+        e4, n4, k4, _ = self.la4(xyz=x4, base_xyz=x3, normal=n3, feature=e3, FPS_idx=p3, xyz_flag=False)
+
+        geo = dict(FPS_0=p0, FPS_1=p1, FPS_2=p2, FPS_3=p3, knn_0=k0, knn_1=k1, knn_2=k2, knn_3=k3, knn_4=k4,
+                   xyz0=x0, xyz1=x1, xyz2=x2, xyz3=x3, xyz4=x4)
+        # decoder: upsample -> Linear -> self-state LocalMerge -> cross-state Fuse, coarse to fine
+        d4 = self.mlp(e4)
+        d4 = self.fuse1(N // 16, f0=e0, f1=e1, f2=e2, f3=e3, f4=d4, **geo)[4]
+        d3 = self.la4_up(xyz=x3, base_xyz=x3, normal=n3, feature=self.up_conv4(upsample(d4, k4)))[0]
+        d3 = self.fuse2(N // 8, f0=e0, f1=e1, f2=e2, f3=d3, f4=e4, **geo)[3]
+        d2 = self.la3_up(xyz=x2, base_xyz=x2, normal=n2, feature=self.up_conv3(upsample(d3, k3)))[0]
+        d2 = self.fuse3(N // 4, f0=e0, f1=e1, f2=d2, f3=e3, f4=e4, **geo)[2]
+        d1 = self.la2_up(xyz=x1, base_xyz=x1, normal=n1, feature=self.up_conv2(upsample(d2, k2)))[0]
+        d1 = self.fuse4(N // 2, f0=e0, f1=d1, f2=e2, f3=e3, f4=e4, **geo)[1]
+        d0 = self.la1_up(xyz=x0, base_xyz=x0, normal=n0, feature=self.up_conv1(upsample(d1, k1)))[0]
+        d0 = self.fuse5(N, f0=d0, f1=e1, f2=e2, f3=e3, f4=e4, **geo)[0]
+
+        glob = torch.cat([t.max(dim=1, keepdim=True)[0] for t in (d0, d1, d2, d3, d4)], dim=2)
+        glob = glob.expand(-1, N, -1)
+        lab = self.conv7(label).expand(-1, N, -1)
+        final = torch.cat((self.conv5(d0), glob, lab), 2)
+        return x0, final
+
+
+class PointNetFeaturePropagation(nn.Module):
+    """3-NN inverse-distance interpolation + Linear (reference :860-912)."""
+
+    def __init__(self, in_channel, mlp, act=False):
+        super().__init__()
+        self.mlp_convs = nn.ModuleList()
+        self.mlp_bns = nn.ModuleList()
+        last_channel = in_channel
+        for out_channel in mlp:
+            self.mlp_convs.append(nn.Conv1d(last_channel, out_channel, 1))
+            self.mlp_bns.append(nn.BatchNorm1d(out_channel))
+            last_channel = out_channel
+        self.act = act
+        self.conv = Linear(in_channel, out_channel, bn=False, act=self.act)
+
+    def forward(self, xyz1, xyz2, points1, points2):
+        return self.conv(three_interpolate(xyz1, xyz2, points2))

@@ -1,0 +1,152 @@
+"""Drop-in for the reference's modules/repsurface_utils.py on MI355X (classification tree):
+same names, signatures and state-dict keys; device work in libmpa_hip.so.
+
+Reference locations (Markov_Process_Analysis_on_Point_Cloud/modules/repsurface_utils.py):
+  sample_and_group:12  square_distance:129  farthest_point_sample:150  index_points:174
+  knn_point:193  SurfaceAbstractionCD:256  Linear:380  LocalMerge:406  LocalTrans:448
+  KeepHighResolutionModule:542
+The RepSurf umbrella/polar feature engineering (UmbrellaSurfaceConstructor, polar_utils,
+recons_utils) is outside the Markov path and is not provided.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..ops import (farthest_point_sample, index_points, knn_point, query_ball_point, query_knn_point,  # noqa: F401
+                   sample, square_distance)
+from .pointnet2_utils import Linear, LocalTrans
+
+
+def sample_and_group(npoint, radius, nsample, center, normal, feature, return_normal=True, return_polar=False,
+                     cuda=False):
+    """reference :12-56 -- FPS, ball query, centre-relative grouping of xyz | normal | feature.
+    `return_polar` needs the out-of-scope polar front-end and is rejected."""
+    if return_polar:
+        raise NotImplementedError("polar features belong to the RepSurf front-end (out of scope, SURVEY.md 8f)")
+    fps_idx = farthest_point_sample(center, npoint)
+    new_center = index_points(center, fps_idx)
+    new_normal = index_points(normal, fps_idx)
+    idx = query_ball_point(radius, nsample, center, new_center, cuda=cuda)
+    group_normal = index_points(normal, idx)
+    group_center_norm = index_points(center, idx) - new_center.unsqueeze(2)
+    if feature is not None:
+        group_feature = index_points(feature, idx)
+        parts = [group_center_norm, group_normal, group_feature] if return_normal else [group_center_norm,
+                                                                                       group_feature]
+    else:
+        parts = [group_center_norm, group_normal]
+    return new_center, new_normal, torch.cat(parts, dim=-1)
+
+
+class SurfaceAbstractionCD(nn.Module):
+    """RepSurf set abstraction (reference :256-319): FPS + ball query + shared MLP + max over
+    the group.  The grouping runs on the gfx950 kernels; the 1x1 convolutions are plain torch."""
+
+    def __init__(self, npoint, radius, nsample, feat_channel, pos_channel, mlp, group_all, return_normal=True,
+                 return_polar=False, cuda=False):
+        super().__init__()
+        if group_all:
+            raise NotImplementedError("group_all is not on the Markov path")
+        self.npoint, self.radius, self.nsample = npoint, radius, nsample
+        self.return_normal, self.return_polar = return_normal, return_polar
+        self.cuda_ops = cuda
+        self.pos_channel = pos_channel
+        self.group_all = group_all
+        self.mlp_convs = nn.ModuleList()
+        self.mlp_bns = nn.ModuleList()
+        self.mlp_l0 = nn.Conv2d(pos_channel, mlp[0], 1)
+        self.mlp_f0 = nn.Conv2d(feat_channel, mlp[0], 1)
+        self.bn_l0 = nn.BatchNorm2d(mlp[0])
+        self.bn_f0 = nn.BatchNorm2d(mlp[0])
+        last = mlp[0]
+        for out_channel in mlp[1:]:
+            self.mlp_convs.append(nn.Conv2d(last, out_channel, 1))
+            self.mlp_bns.append(nn.BatchNorm2d(out_channel))
+            last = out_channel
+
+    def forward(self, center, normal, feature):
+        normal = normal.permute(0, 2, 1).contiguous()
+        center = center.permute(0, 2, 1).contiguous()
+        if feature is not None:
+            feature = feature.permute(0, 2, 1).contiguous()
+        new_center, new_normal, new_feature = sample_and_group(self.npoint, self.radius, self.nsample, center, normal,
+                                                               feature, return_normal=self.return_normal,
+                                                               return_polar=self.return_polar, cuda=self.cuda_ops)
+        new_feature = new_feature.permute(0, 3, 2, 1)
+        loc = self.bn_l0(self.mlp_l0(new_feature[:, :self.pos_channel]))
+        feat = self.bn_f0(self.mlp_f0(new_feature[:, self.pos_channel:]))
+        new_feature = F.relu(loc + feat)
+        for conv, bn in zip(self.mlp_convs, self.mlp_bns):
+            new_feature = F.relu(bn(conv(new_feature)))
+        new_feature = torch.max(new_feature, 2)[0]
+        return new_center.permute(0, 2, 1), new_normal.permute(0, 2, 1), new_feature
+
+
+class LocalMerge(nn.Module):
+    """State -> state probability-transition block, classification variant (reference :406-446):
+    xyz-space and feature-space neighbourhoods, two attention streams, fc2 over 2*out.
+    `normal` is returned un-indexed, as in the reference (:446)."""
+
+    def __init__(self, in_channels, out_channels, knn, usetanh=False, residual=False):
+        super().__init__()
+        self.knn = knn
+        self.usetanh = usetanh
+        self.residual = residual
+        self.fc1 = Linear(out_channels * 2, out_channels, bn=False)
+        self.fc2 = Linear(out_channels * 2, out_channels, bn=False)
+        self.xyz_Trans = LocalTrans(3, out_channels, knn, usetanh=usetanh, residual=True)
+        self.normal_Trans = LocalTrans(10, out_channels, knn, usetanh=usetanh, residual=True)
+        self.feature_Trans = LocalTrans(in_channels, out_channels, knn, usetanh=usetanh, residual=residual)
+        self.feature_Trans2 = LocalTrans(in_channels, out_channels, knn, usetanh=usetanh, residual=residual)
+
+    def forward(self, xyz, base_xyz, normal=None, feature=None, FPS_idx=None, xyz_flag=True):
+        dist, idx = knn_point(self.knn, base_xyz, xyz)
+        if feature is None:
+            merge_features = self.xyz_Trans(features=xyz, idx=idx, pos=base_xyz, FPS_idx=FPS_idx, xyz=True)
+        else:
+            fs = feature if FPS_idx is None else index_points(feature, FPS_idx)
+            _, idx_feature = knn_point(self.knn, feature, fs)
+            f1 = self.feature_Trans(features=feature, idx=idx, pos=base_xyz, FPS_idx=FPS_idx)
+            f2 = self.feature_Trans2(features=feature, idx=idx_feature, pos=base_xyz, FPS_idx=FPS_idx)
+            merge_features = self.fc2(torch.cat((f1, f2), dim=2))
+        return merge_features, normal, idx, dist
+
+
+class KeepHighResolutionModule(nn.Module):
+    """Classification encoder wiring (reference :542-639): la0 on the full cloud, then five
+    FPS halvings (512..32 for N=1024) each followed by a LocalMerge, conv3/conv4, max|avg pool,
+    final_class + BN + LeakyReLU -> [B,1024]."""
+
+    def __init__(self, data_C, b1_C, b2_C, b3_C, b4_C, cuda=False):
+        super().__init__()
+        self.cuda_ops = cuda   # the reference stores this as `self.cuda`, shadowing nn.Module.cuda
+        self.drop = nn.Dropout(0.5)
+        self.la0 = LocalMerge(32, 64, 8, usetanh=False, residual=True)
+        self.la1 = LocalMerge(64, 64, 8, usetanh=False, residual=False)
+        self.la2 = LocalMerge(64, 64, 8, usetanh=False, residual=False)
+        self.la3 = LocalMerge(64, 128, 8, usetanh=False, residual=True)
+        self.la4 = LocalMerge(128, 256, 8, usetanh=False, residual=True)
+        self.la5 = LocalMerge(256, 512, 8, usetanh=False, residual=True)
+        self.start = Linear(3, 32, bn=False)
+        self.conv3 = Linear(512, 512, bn=False)
+        self.conv4 = Linear(512, 1024, bn=False)
+        self.final = Linear(512, 1024, bn=False)
+        self.final_class = nn.Linear(2048, 1024)
+        self.bn = nn.BatchNorm1d(1024)
+        self.lrelu = nn.LeakyReLU(negative_slope=0.2)
+
+    # the reference hard-codes 512/256/128/64/32 for its 1024-point input
+    LEVELS = (512, 256, 128, 64, 32)
+
+    def forward(self, xyz, normal):
+        xyz = xyz.permute(0, 2, 1).contiguous()
+        normal = normal.permute(0, 2, 1).contiguous()
+        feat, normal, _, _ = self.la0(xyz=xyz, base_xyz=xyz, normal=normal, xyz_flag=True)
+        base = xyz
+        for npoint, la in zip(self.LEVELS, (self.la1, self.la2, self.la3, self.la4, self.la5)):
+            fps_idx, sub = farthest_point_sample(base, npoint, return_xyz=True)
+            feat, normal, _, _ = la(xyz=sub, base_xyz=base, normal=normal, feature=feat, FPS_idx=fps_idx)
+            base = sub
+        final = self.conv4(self.conv3(feat))                       # [B,32,1024]
+        fused = torch.cat((final.max(dim=1)[0], final.mean(dim=1)), 1)
+        return self.lrelu(self.bn(self.final_class(fused)))

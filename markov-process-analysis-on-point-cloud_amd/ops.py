@@ -1,0 +1,348 @@
+"""Device ops of the Markov set-abstraction path: thin torch wrappers over the C ABI of
+libmpa_hip.so.  torch owns memory, streams and autograd plumbing; all arithmetic of the path
+runs in the hand-written gfx950 kernels.  There is no CPU path here: every op raises on
+non-CUDA tensors (the CPU oracle under oracle/ is test infrastructure and is never imported).
+
+Function names and argument order follow the reference's modules/pointnet2_utils.py
+(== modules/repsurface_utils.py); legacy keyword arguments used by the reference's callers
+(`cuda=`, `is_group=`) are accepted and ignored.
+"""
+import ctypes
+
+import torch
+
+from ._lib import lib, check
+
+_vp = ctypes.c_void_p
+
+
+def _p(t):
+    return _vp(t.data_ptr()) if t is not None else _vp(0)
+
+
+def _stream():
+    return _vp(torch.cuda.current_stream().cuda_stream)
+
+
+# Optional per-kernel timing (bench.py's roofline leg): HIP events are recorded on the stream
+# the kernel is launched on (torch's current stream) around the named entry points only.
+_TIMERS = None
+
+
+def enable_kernel_timing(names):
+    global _TIMERS
+    _TIMERS = {n: [] for n in names}
+
+
+def disable_kernel_timing():
+    global _TIMERS
+    _TIMERS = None
+
+
+def kernel_timing_results():
+    """-> {name: {"launches": n, "ms": total_ms, "algo_bytes": total_bytes}} (synchronises)."""
+    torch.cuda.synchronize()
+    out = {}
+    for name, recs in (_TIMERS or {}).items():
+        out[name] = {"launches": len(recs), "ms": sum(a.elapsed_time(b) for a, b, _ in recs),
+                     "algo_bytes": sum(n for _, _, n in recs)}
+    return out
+
+
+def _launch(name, *args, algo_bytes=0):
+    fn = getattr(lib, name)
+    recs = _TIMERS.get(name) if _TIMERS is not None else None
+    if recs is None:
+        check(fn(*args), name)
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    check(fn(*args), name)
+    e1.record()
+    recs.append((e0, e1, algo_bytes))
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("mpa_amd ops need CUDA (ROCm) tensors; there is no CPU fallback in the product path")
+
+
+def _f32(t):
+    if t.dtype != torch.float32:
+        raise TypeError("expected float32, got %s" % t.dtype)
+    return t.contiguous()
+
+
+def _i64(t):
+    return t.to(torch.int64).contiguous()
+
+
+# ------------------------------------------------------------------------------- sampling
+def farthest_point_sample(xyz, npoint, cuda=False, start_idx=None, return_xyz=False):
+    """reference: modules/pointnet2_utils.py:84-109.  xyz [B,N,3] -> int64 [B,npoint].
+    The first index of every cloud comes from the global CPU generator exactly as in the
+    reference (torch.randint on CPU, then moved), so equal seeds give equal samples."""
+    _dev(xyz)
+    xyz = _f32(xyz)
+    B, N, C = xyz.shape
+    if C != 3:
+        raise ValueError("farthest_point_sample: the gfx950 kernel samples in xyz space (C == 3), got C=%d" % C)
+    if start_idx is None:
+        start_idx = torch.randint(0, N, (B,), dtype=torch.long)
+    start = start_idx.to(device=xyz.device, dtype=torch.int64).contiguous()
+    if int(start_idx.min()) < 0 or int(start_idx.max()) >= N:
+        raise ValueError("farthest_point_sample: start_idx out of range")
+    out = torch.empty(B, npoint, dtype=torch.int64, device=xyz.device)
+    oxyz = torch.empty(B, npoint, 3, dtype=torch.float32, device=xyz.device) if return_xyz else None
+    _launch("mpa_fps_f32", _p(xyz), B, N, npoint, _p(start), _p(out), _p(oxyz), _stream())
+    return (out, oxyz) if return_xyz else out
+
+
+def sample(nsample, feature, cuda=False):
+    """Legacy helper the reference's train loop calls but never defines
+    (tool/train_cls_scanobjectnn.py:244): FPS-downsample a channel-first batch
+    [B,C,N] -> [B,C,nsample] using the first three channels as coordinates."""
+    pts = feature.transpose(1, 2).contiguous()
+    idx = farthest_point_sample(pts[:, :, :3].contiguous(), nsample)
+    return index_points(pts, idx).transpose(1, 2).contiguous()
+
+
+# ------------------------------------------------------------------------------- distances
+def square_distance(src, dst):
+    """reference: modules/pointnet2_utils.py:190-209.  [B,S,C],[B,N,C] -> [B,S,N] (bit-exact)."""
+    _dev(src, dst)
+    src, dst = _f32(src), _f32(dst)
+    B, S, C = src.shape
+    N = dst.shape[1]
+    out = torch.empty(B, S, N, dtype=torch.float32, device=src.device)
+    _launch("mpa_square_distance_f32", _p(src), _p(dst), B, S, N, C, _p(out), _stream())
+    return out
+
+
+def knn_point(nsample, xyz, new_xyz):
+    """reference: modules/pointnet2_utils.py:211-222.  Returns (dist [B,S,k], idx int64 [B,S,k]),
+    ascending.  Indices are not differentiable; dist carries no gradient (the models never use it)."""
+    _dev(xyz, new_xyz)
+    base, query = _f32(xyz.detach()), _f32(new_xyz.detach())
+    B, N, C = base.shape
+    S = query.shape[1]
+    dist = torch.empty(B, S, nsample, dtype=torch.float32, device=base.device)
+    idx = torch.empty(B, S, nsample, dtype=torch.int64, device=base.device)
+    _launch("mpa_knn_f32", _p(base), _p(query), B, N, S, C, nsample, _p(dist), _p(idx), _stream(),
+            algo_bytes=B * (4 * C * (S + N) + 12 * S * nsample))
+    return dist, idx
+
+
+def query_knn_point(k, xyz, new_xyz, cuda=False):
+    """Legacy name used by modules/repsurface_utils.py:111 and recons_utils.py (defined nowhere
+    in the reference): indices only."""
+    return knn_point(k, xyz, new_xyz)[1]
+
+
+def query_ball_point(radius, nsample, xyz, new_xyz, cuda=False):
+    """reference: modules/pointnet2_utils.py:112-134."""
+    _dev(xyz, new_xyz)
+    base, query = _f32(xyz.detach()), _f32(new_xyz.detach())
+    B, N, C = base.shape
+    S = query.shape[1]
+    idx = torch.empty(B, S, nsample, dtype=torch.int64, device=base.device)
+    r2 = float(torch.tensor(radius ** 2, dtype=torch.float32))   # the compare happens in fp32
+    _launch("mpa_ball_query_f32", _p(base), _p(query), B, N, S, C, r2, nsample, _p(idx), _stream())
+    return idx
+
+
+def three_nn(xyz1, xyz2):
+    """3 nearest xyz2 rows for every xyz1 row, as PointNetFeaturePropagation sorts them
+    (modules/pointnet2_utils.py:899-901) -> (dist [B,N,3], idx [B,N,3])."""
+    return knn_point(3, xyz2, xyz1)
+
+
+# ------------------------------------------------------------------------------- gathers
+class _IndexPoints(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, points, idx):
+        B, N, C = points.shape
+        flat = idx.reshape(B, -1)
+        M = flat.shape[1]
+        out = torch.empty(B, M, C, dtype=torch.float32, device=points.device)
+        _launch("mpa_gather_fwd_f32", _p(points), _p(flat), B, N, M, C, _p(out), _stream())
+        ctx.save_for_backward(flat)
+        ctx.shape = (B, N, M, C)
+        return out.view(*idx.shape, C)
+
+    @staticmethod
+    def backward(ctx, grad):
+        (flat,) = ctx.saved_tensors
+        B, N, M, C = ctx.shape
+        grad = grad.contiguous()
+        gp = torch.zeros(B, N, C, dtype=torch.float32, device=grad.device)
+        _launch("mpa_gather_bwd_f32", _p(grad), _p(flat), B, N, M, C, _p(gp), _stream())
+        return gp, None
+
+
+def index_points(points, idx, cuda=False, is_group=False):
+    """reference: modules/pointnet2_utils.py:64-81.  points [B,N,C], idx [B,S] or [B,S,K]."""
+    _dev(points, idx)
+    if points.dtype != torch.float32:
+        # index-map composition etc. (integer payloads): plain device indexing
+        B = points.shape[0]
+        bidx = torch.arange(B, device=points.device).view([B] + [1] * (idx.dim() - 1)).expand_as(idx)
+        return points[bidx, idx, :]
+    return _IndexPoints.apply(points.contiguous(), _i64(idx))
+
+
+# ------------------------------------------------------------------------------- attention
+class _DiffAttn(torch.autograd.Function):
+    """ctx = max_j (softmax_j((q-k_j)/sqrt(C)) - sum) * v_j with k|v = the two halves of kv."""
+
+    @staticmethod
+    def forward(ctx, q, kv, idx):
+        B, S, C = q.shape
+        N = kv.shape[1]
+        K = idx.shape[2]
+        out = torch.empty_like(q)
+        argk = torch.empty(B, S, C, dtype=torch.uint8, device=q.device)
+        k = kv
+        v = kv[:, :, C:]
+        _launch("mpa_diffattn_fwd_f32", _p(q), _p(k), _vp(v.data_ptr()), 2 * C, _p(idx), B, N, S, K, C, _p(out),
+                _p(argk), _stream(), algo_bytes=B * S * (4 * (2 * C + 2 * K * C) + 8 * K + C))
+        ctx.save_for_backward(q, kv, idx, argk)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        q, kv, idx, argk = ctx.saved_tensors
+        B, S, C = q.shape
+        N = kv.shape[1]
+        K = idx.shape[2]
+        grad = grad.contiguous()
+        gq = torch.empty_like(q)
+        gkv = torch.zeros_like(kv)
+        _launch("mpa_diffattn_bwd_f32", _p(q), _p(kv), _vp(kv.data_ptr() + 4 * C), 2 * C, _p(idx), _p(argk), _p(grad),
+                                       B, N, S, K, C, _p(gq), _p(gkv), _vp(gkv.data_ptr() + 4 * C), 2 * C, _stream())
+        return gq, gkv, None
+
+
+def diffattn(q, kv, idx):
+    """Difference-wise attention core of LocalTrans' feature branch
+    (modules/pointnet2_utils.py:558-569).  q [B,S,C]; kv [B,N,2C] = projected keys | values;
+    idx [B,S,K] -> ctx [B,S,C]."""
+    _dev(q, kv, idx)
+    return _DiffAttn.apply(_f32(q), _f32(kv), _i64(idx))
+
+
+class _DiffAttnXYZ(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xyz, center, idx, Wq, bq, Wk, bk, Wv, bv):
+        B, N, _ = xyz.shape
+        S, K = idx.shape[1], idx.shape[2]
+        C = Wq.shape[0]
+        out = torch.empty(B, S, C, dtype=torch.float32, device=xyz.device)
+        argk = torch.empty(B, S, C, dtype=torch.uint8, device=xyz.device)
+        params = [t.contiguous() for t in (Wq, bq, Wk, bk, Wv, bv)]
+        _launch("mpa_diffattn_xyz_fwd_f32", _p(xyz), _p(center), _p(idx), *[_p(t) for t in params], B, N, S, K, C,
+                                           _p(out), _p(argk), _stream())
+        ctx.save_for_backward(xyz, center, idx, argk, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        xyz, center, idx, argk, Wq, bq, Wk, bk, Wv, bv = ctx.saved_tensors
+        B, N, _ = xyz.shape
+        S, K = idx.shape[1], idx.shape[2]
+        C = Wq.shape[0]
+        grad = grad.contiguous()
+        gs = [torch.zeros_like(t) for t in (Wq, bq, Wk, bk, Wv, bv)]
+        _launch("mpa_diffattn_xyz_bwd_f32", _p(xyz), _p(center), _p(idx), _p(Wq), _p(bq), _p(Wk), _p(bk), _p(Wv),
+                                           _p(bv), _p(argk), _p(grad), B, N, S, K, C, *[_p(g) for g in gs],
+                                           _stream())
+        return (None, None, None) + tuple(gs)
+
+
+def diffattn_xyz(xyz, center, idx, Wq, bq, Wk, bk, Wv, bv):
+    """LocalTrans' xyz branch (modules/pointnet2_utils.py:518-544) on raw coordinates:
+    xyz [B,N,3] base, center [B,S,3], idx [B,S,K]; W* [C,3], b* [C] -> ctx [B,S,C].
+    Coordinates are network inputs and receive no gradient."""
+    _dev(xyz, center, idx, Wq)
+    return _DiffAttnXYZ.apply(_f32(xyz.detach()), _f32(center.detach()), _i64(idx), Wq, bq, Wk, bk, Wv, bv)
+
+
+# ------------------------------------------------------------------------------- decoder
+class _UpsampleMean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, points, knn_idx, n_fine):
+        B, S, C = points.shape
+        K = knn_idx.shape[2]
+        out = torch.empty(B, n_fine, C, dtype=torch.float32, device=points.device)
+        cnt = torch.empty(B, n_fine, dtype=torch.float32, device=points.device)
+        _launch("mpa_upsample_mean_fwd_f32", _p(points), _p(knn_idx), B, S, K, n_fine, C, _p(out), _p(cnt), _stream())
+        ctx.save_for_backward(knn_idx, cnt)
+        ctx.shape = (B, S, K, n_fine, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        knn_idx, cnt = ctx.saved_tensors
+        B, S, K, n_fine, C = ctx.shape
+        grad = grad.contiguous()
+        gp = torch.empty(B, S, C, dtype=torch.float32, device=grad.device)
+        _launch("mpa_upsample_mean_bwd_f32", _p(grad), _p(knn_idx), _p(cnt), B, S, K, n_fine, C, _p(gp), _stream())
+        return gp, None, None
+
+
+def upsample(points, knn_idx, scale_ratio=2, dist=None):
+    """reference: modules/pointnet2_utils.py:13-50 (coarse->fine transition).  points [B,S,C],
+    knn_idx [B,S,K] (values < S*scale_ratio) -> [B,S*scale_ratio,C].  `dist` is unused, as in
+    the reference.  Note: the divisor depends on which channel-0 values are exactly zero; like
+    the reference, that dependence is not differentiated."""
+    _dev(points, knn_idx)
+    n_fine = points.shape[1] * scale_ratio
+    return _UpsampleMean.apply(_f32(points), _i64(knn_idx), n_fine)
+
+
+class _ThreeInterp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, points2, idx, dist):
+        B, Nb, C = points2.shape
+        Nq = idx.shape[1]
+        out = torch.empty(B, Nq, C, dtype=torch.float32, device=points2.device)
+        _launch("mpa_three_interp_fwd_f32", _p(points2), _p(idx), _p(dist), B, Nq, Nb, C, _p(out), _stream())
+        ctx.save_for_backward(idx, dist)
+        ctx.shape = (B, Nq, Nb, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        idx, dist = ctx.saved_tensors
+        B, Nq, Nb, C = ctx.shape
+        grad = grad.contiguous()
+        gp = torch.zeros(B, Nb, C, dtype=torch.float32, device=grad.device)
+        _launch("mpa_three_interp_bwd_f32", _p(grad), _p(idx), _p(dist), B, Nq, Nb, C, _p(gp), _stream())
+        return gp, None, None
+
+
+def three_interpolate(xyz1, xyz2, points2):
+    """Inverse-distance 3-NN interpolation of PointNetFeaturePropagation
+    (modules/pointnet2_utils.py:896-906): xyz1 [B,N,3] fine, xyz2 [B,S,3] coarse, points2 [B,S,D]."""
+    _dev(xyz1, xyz2, points2)
+    if xyz2.shape[1] == 1:
+        return points2.repeat(1, xyz1.shape[1], 1)
+    dist, idx = three_nn(xyz1, xyz2)
+    return _ThreeInterp.apply(_f32(points2), idx, dist)
+
+
+# ------------------------------------------------------------------------------- transition MLP
+def linear(x, weight, bias):
+    """y = x W^T + b over the last dimension."""
+    return torch.nn.functional.linear(x, weight, bias)
+
+
+def linear_bn_act(x, weight, bias, bn, slope):
+    """The reference's Linear unit (modules/pointnet2_utils.py:413-425): affine, BatchNorm1d
+    over the B*S rows (batch statistics in training, running statistics in eval; `bn` is the
+    nn.BatchNorm1d holding gamma/beta/running stats), LeakyReLU(slope) unless slope is None."""
+    B, S, _ = x.shape
+    y = torch.nn.functional.linear(x, weight, bias)
+    y = bn(y.view(B * S, -1)).view(B, S, -1)
+    return torch.nn.functional.leaky_relu(y, slope) if slope is not None else y

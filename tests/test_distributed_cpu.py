@@ -1,0 +1,93 @@
+"""world_size-2 gloo tests of the data-parallel helpers (CPU; the model is a plain torch
+stand-in -- the reducer is host logic and does not depend on the HIP kernels)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+class _Net(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.body = torch.nn.Sequential(torch.nn.Linear(8, 32), torch.nn.LeakyReLU(0.2), torch.nn.Linear(32, 32),
+                                        torch.nn.LeakyReLU(0.2), torch.nn.Linear(32, 4))
+        self.unused = torch.nn.Linear(5, 5)   # never receives a gradient (like normal_Trans / fc1)
+
+    def forward(self, x):
+        return self.body(x)
+
+
+def _make_model():
+    torch.manual_seed(0)
+    return _Net()
+
+
+def _data():
+    g = torch.Generator().manual_seed(1)
+    return torch.randn(12, 8, generator=g), torch.randn(12, 4, generator=g)
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import mpa_amd  # noqa: F401
+    from mpa_amd import distributed as md
+    md.init_process_group("gloo")
+    assert md.world_size() == world and md.rank() == rank
+    model = _make_model()
+    red = md.GradReducer(model, bucket_bytes=2048)      # small buckets: several per model
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    x, y = _data()
+    lo, hi = md.shard_batch(x.shape[0])
+    for _ in range(3):
+        red.zero_grad()
+        # mean over the GLOBAL batch = mean over ranks of (local sum / local count) when shards are equal
+        loss = ((model(x[lo:hi]) - y[lo:hi]) ** 2).mean()
+        loss.backward()
+        red.all_reduce()
+        opt.step()
+    assert len(red.buckets) > 1
+    assert model.unused.weight.grad is None
+    t = md.max_over_ranks(float(rank))
+    assert t == world - 1
+    if rank == 0:
+        torch.save({k: v.clone() for k, v in model.state_dict().items()}, out)
+    md.barrier()
+    md.shutdown()
+
+
+def test_grad_reducer_matches_single_process(tmp_path):
+    world, port, out = 2, _free_port(), str(tmp_path / "dp.pt")
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    dp = torch.load(out, weights_only=True)
+    model = _make_model()
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    x, y = _data()
+    for _ in range(3):
+        opt.zero_grad()
+        ((model(x) - y) ** 2).mean().backward()
+        opt.step()
+    for k, v in model.state_dict().items():
+        assert torch.allclose(v, dp[k], atol=1e-6), k
+
+
+def test_shard_batch_partitions():
+    import mpa_amd  # noqa: F401
+    from mpa_amd.distributed import shard_batch
+    for n in (1, 7, 64, 65):
+        for w in (1, 2, 3, 8):
+            parts = [shard_batch(n, r, w) for r in range(w)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))
+            sizes = [b - a for a, b in parts]
+            assert max(sizes) - min(sizes) <= 1

@@ -1,0 +1,278 @@
+"""GPU parity tests of the L1 blocks and whole models: the HIP path against golden vectors
+produced by the reference (features within 1e-4 as BASELINE.json's north_star states; indices
+exact).  Weights come from the same name-hashed fill as in make_golden.py."""
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+
+from param_fill import fill_state, randn
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4   # fp32 feature tolerance (north_star); gradients: TOL * max(1, |ref|_max)
+
+
+@pytest.fixture(scope="module")
+def P():
+    import mpa_amd  # noqa: F401
+    from mpa_amd.modules import pointnet2_utils
+    assert torch.cuda.is_available()
+    return pointnet2_utils
+
+
+@pytest.fixture(scope="module")
+def RS():
+    from mpa_amd.modules import repsurface_utils
+    return repsurface_utils
+
+
+def G(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def GL(a):
+    return torch.from_numpy(np.ascontiguousarray(a).astype(np.int64)).cuda()
+
+
+def close(got, ref, tol=TOL, what="", scale=None):
+    """max |got - ref| < tol * max(1, scale); scale defaults to |ref|_max.  For parameter
+    gradients `scale` is the largest gradient entry of the whole block: a gradient that is a
+    heavily cancelling sum (e.g. any bias in front of a train-mode BatchNorm, whose exact
+    gradient is 0) carries fp32 noise proportional to the terms it sums, not to its own size --
+    the reference's own fp32 result differs from an fp64 evaluation by that much."""
+    got = got.detach().cpu().numpy() if torch.is_tensor(got) else got
+    err = np.abs(got - ref).max()
+    lim = tol * max(1.0, float(np.abs(ref).max()) if scale is None else scale)
+    assert err < lim, "%s: max err %.3e > %.3e" % (what, err, lim)
+
+
+def grad_scale(g, prefix):
+    return max(float(np.abs(v).max()) for k, v in g.items() if k.startswith(prefix + "/g"))
+
+
+@pytest.mark.parametrize("tag,ci,co_,act", [("lin_a", 64, 128, True), ("lin_b", 3, 64, True), ("lin_c", 128, 64, False)])
+def test_linear(P, golden_blocks, tag, ci, co_, act):
+    g = golden_blocks
+    m = fill_state(P.Linear(ci, co_, bn=False, act=act), seed=1).cuda().train()
+    x = G(g[tag + "/x"]).requires_grad_(True)
+    y = m(x)
+    close(y, g[tag + "/y_train"], what="y_train")
+    y.backward(randn(y.shape, seed=4242).cuda())
+    gs = grad_scale(g, tag)
+    close(x.grad, g[tag + "/gx"], what="gx")
+    close(m.linear.weight.grad, g[tag + "/gw"], what="gw", scale=gs)
+    close(m.linear.bias.grad, g[tag + "/gb"], what="gb", scale=gs)
+    close(m.norm2.weight.grad, g[tag + "/ggamma"], what="ggamma", scale=gs)
+    close(m.norm2.bias.grad, g[tag + "/gbeta"], what="gbeta", scale=gs)
+    close(m.norm2.running_mean, g[tag + "/running_mean"], tol=1e-5, what="running_mean")
+    close(m.norm2.running_var, g[tag + "/running_var"], tol=1e-5, what="running_var")
+    m = fill_state(P.Linear(ci, co_, bn=False, act=act), seed=1).cuda().eval()
+    close(m(x), g[tag + "/y_eval"], what="y_eval")
+
+
+LT_CASES = {"lt_xyz_self": (3, 64, True, False, True), "lt_xyz_fps": (3, 64, True, True, True),
+            "lt_feat_id": (64, 64, False, True, False), "lt_feat_res": (64, 128, True, True, False),
+            "lt_feat_self": (32, 32, False, False, False)}
+
+
+@pytest.mark.parametrize("tag", sorted(LT_CASES))
+def test_local_trans(P, golden_blocks, tag):
+    g = golden_blocks
+    ci, co_, residual, use_fps, is_xyz = LT_CASES[tag]
+    m = fill_state(P.LocalTrans(ci, co_, 8, residual=residual), seed=2).cuda().train()
+    f = G(g[tag + "/f"]).requires_grad_(not is_xyz)
+    idx = GL(g["geo/idx"] if use_fps else g["geo/idx_self"])
+    fps = GL(g["geo/fps"]) if use_fps else None
+    out = m(f, idx, G(g["geo/xyz"]), FPS_idx=fps, xyz=is_xyz)
+    close(out, g[tag + "/out"], what="out")
+    out.backward(randn(out.shape, seed=4242).cuda())
+    if not is_xyz:
+        close(f.grad, g[tag + "/gf"], what="gf")
+    gs = grad_scale(g, tag)
+    for n, p in m.named_parameters():
+        key = tag + "/g." + n
+        if key in g:
+            close(p.grad, g[key], what=n, scale=gs)
+        else:
+            assert p.grad is None, n
+    m.eval()
+    close(m(f, idx, G(g["geo/xyz"]), FPS_idx=fps, xyz=is_xyz), g[tag + "/out_eval"], what="out_eval")
+
+
+@pytest.mark.parametrize("tag", ["lm_cls", "lm_seg"])
+def test_local_merge(P, RS, golden_blocks, tag):
+    g = golden_blocks
+    cls = RS.LocalMerge if tag == "lm_cls" else P.LocalMerge
+    xyz, fps = G(g["geo/xyz"]), GL(g["geo/fps"])
+    sub = P.index_points(xyz, fps)
+    m0 = fill_state(cls(32, 64, 8, residual=True), seed=3).cuda().train()
+    f0, _, i0, d0 = m0(xyz=xyz, base_xyz=xyz, normal=xyz)
+    assert np.array_equal(i0.cpu().numpy(), g[tag + "/idx0"])
+    assert np.array_equal(d0.cpu().numpy().view(np.int32), g[tag + "/dist0"].view(np.int32))
+    close(f0, g[tag + "/f0"], what="f0")
+    m1 = fill_state(cls(64, 64, 8, residual=False), seed=4).cuda().train()
+    feat = G(g[tag + "/f0"]).requires_grad_(True)      # identical input => identical feature-kNN
+    f1, n1, i1, _ = m1(xyz=sub, base_xyz=xyz, normal=xyz, feature=feat, FPS_idx=fps)
+    assert np.array_equal(i1.cpu().numpy(), g[tag + "/idx1"])
+    close(f1, g[tag + "/f1"], what="f1")
+    f1.backward(randn(f1.shape, seed=4242).cuda())
+    close(feat.grad, g[tag + "/gfeat"], what="gfeat")
+    assert bool(g[tag + "/normal1_is_indexed"]) == (n1.shape[1] == sub.shape[1])
+    # the block's feature-space neighbourhoods equal the reference's
+    _, idx_f = P.knn_point(8, feat.detach(), P.index_points(feat.detach(), fps))
+    assert np.array_equal(idx_f.cpu().numpy(), g[tag + "/idx1_feat"])
+
+
+def test_upsample(P, golden_blocks):
+    g = golden_blocks
+    pts = G(g["up/pts"]).requires_grad_(True)
+    up = P.upsample(pts, GL(g["up/idx"]))
+    close(up, g["up/out"], tol=1e-6, what="up")
+    assert int((up.detach().abs().sum(-1) == 0).sum()) == int(g["up/uncovered"]) > 0
+    up.backward(randn(up.shape, seed=4242).cuda())
+    close(pts.grad, g["up/gpts"], tol=1e-6, what="gpts")
+    up4 = P.upsample(G(g["up4/pts"]), GL(g["up4/idx"]), scale_ratio=4)
+    close(up4, g["up4/out"], tol=1e-6, what="up4")
+
+
+def test_feature_propagation(P, golden_blocks):
+    g = golden_blocks
+    xyz, fps = G(g["geo/xyz"]), GL(g["geo/fps"])
+    sub = P.index_points(xyz, fps)
+    m = fill_state(P.PointNetFeaturePropagation(32, [48], act=True), seed=5).cuda().train()
+    p2 = G(g["fp/points2"]).requires_grad_(True)
+    out = m(xyz, sub, None, p2)
+    close(out, g["fp/out"], what="out")
+    out.backward(randn(out.shape, seed=4242).cuda())
+    close(p2.grad, g["fp/gpoints2"], what="gpoints2")
+
+
+def test_fuse(P, golden_fuse):
+    g = golden_fuse
+    x0 = G(g["x0"])
+    fps = [GL(g["fps%d" % l]) for l in range(4)]
+    knn = [GL(g["knn%d" % l]) for l in range(5)]
+    feats = [G(g["f%d" % l]) for l in range(5)]
+    xs = [x0]
+    for p in fps:
+        xs.append(P.index_points(xs[-1], p))
+    m = fill_state(P.Fuse(64, 64, 64, 128, 256), seed=6).cuda().train()
+    for lvl in range(5):
+        out = m(xs[lvl].shape[1], f0=feats[0], f1=feats[1], f2=feats[2], f3=feats[3], f4=feats[4],
+                FPS_0=fps[0], FPS_1=fps[1], FPS_2=fps[2], FPS_3=fps[3],
+                knn_0=knn[0], knn_1=knn[1], knn_2=knn[2], knn_3=knn[3], knn_4=knn[4],
+                xyz0=xs[0], xyz1=xs[1], xyz2=xs[2], xyz3=xs[3], xyz4=xs[4])
+        close(out[lvl], g["out%d" % lvl], what="fuse level %d" % lvl)
+
+
+# ------------------------------------------------------------------------------- whole models
+class _ForcedKnn:
+    """Teacher forcing of the neighbourhood choice for whole-model parity.  GPU features differ
+    from the reference's CPU features by ~1e-6, so a near-tied feature-space neighbour can flip
+    even though the kNN kernel is exact on identical inputs (that is what test_gpu_ops.py and
+    test_local_merge check).  Here the k-th knn_point call returns the reference's recorded
+    indices; the count of calls where the GPU's own choice differed is reported."""
+
+    def __init__(self, real, recorded):
+        self.real, self.recorded, self.i, self.flips, self.total = real, recorded, 0, 0, 0
+
+    def __call__(self, nsample, xyz, new_xyz):
+        dist, idx = self.real(nsample, xyz, new_xyz)
+        ref = self.recorded[self.i].to(idx.device)
+        self.i += 1
+        self.flips += int((idx != ref).any(-1).sum())
+        self.total += idx.shape[0] * idx.shape[1]
+        return dist, ref
+
+
+def _run_model(g, model, run, patch_mods, prefix):
+    rec = [GL(g["%sknn%d" % (prefix, i)]) for i in range(sum(1 for k in g if k.startswith(prefix + "knn")))]
+    forced = _ForcedKnn(patch_mods[0].knn_point, rec)
+    saved = [m.knn_point for m in patch_mods]
+    for m in patch_mods:
+        m.knn_point = forced
+    try:
+        torch.manual_seed(2024)
+        out = run(model)
+    finally:
+        for m, s in zip(patch_mods, saved):
+            m.knn_point = s
+    assert forced.i == len(rec)
+    return out, forced
+
+
+def _check_grads(g, model):
+    """Whole-model gradients are NOT reproducible to 1e-4 even by the reference itself: the nets
+    hold millions of max() selections (attention max over K, LeakyReLU, max-pools), and a
+    ~1e-6 forward perturbation flips a few near-tied arg-maxes, rerouting gradient discontinuously
+    (the oracle evaluated in fp64 differs from the fp32 golden by 5.6e-3 relative L2 on
+    la0.xyz_Trans.k.weight).  1e-4 gradient parity is asserted per block (tests above); here:
+    the same parameters receive gradient, every gradient norm agrees to 2e-2 (+ fp32 noise
+    floor), and the stored full tensors agree to 2e-2 relative L2."""
+    names = list(g["grad_names"])
+    gmax = float(g["grad_norms"].max())
+    for n, p in model.named_parameters():
+        i = names.index(n)
+        assert (p.grad is not None) == bool(g["has_grad"][i]), n
+        if p.grad is not None:
+            ref = float(g["grad_norms"][i])
+            got = float(p.grad.double().norm())
+            assert abs(got - ref) <= 2e-2 * ref + 2e-6 * gmax, "%s: grad norm %g vs %g" % (n, got, ref)
+        if "grad." + n in g:
+            r = g["grad." + n]
+            if np.linalg.norm(r) > 1e-4 * gmax:
+                rel = np.linalg.norm(p.grad.cpu().numpy() - r) / np.linalg.norm(r)
+                assert rel < 2e-2, "%s: relative L2 gradient error %.3e" % (n, rel)
+
+
+def test_cls_model(P, RS, golden_cls):
+    from mpa_amd.models.repsurf.repsurf_ssg_umb import Model
+    g = golden_cls
+    args = Namespace(num_point=1024, return_dist=True, cuda_ops=False, num_class=40)
+    model = fill_state(Model(args), seed=0).cuda()
+    model.drop1.p = model.drop2.p = 0.0
+    pts = G(g["points"])
+    model.eval()
+    with torch.no_grad():
+        out, forced = _run_model(g, model, lambda m: m(pts), [RS], "")
+    print("cls eval: feature-kNN rows differing before forcing: %d / %d" % (forced.flips, forced.total))
+    close(out, g["out_eval"], what="cls eval log-probs")
+    assert forced.flips <= 0.002 * forced.total
+    model.train()
+    out, forced = _run_model(g, model, lambda m: m(pts), [RS], "train_")
+    close(out, g["out_train"], what="cls train log-probs")
+    (out * randn(out.shape, seed=31337).cuda()).sum().backward()
+    _check_grads(g, model)
+
+
+def test_cls_model_unforced(P, RS, golden_cls):
+    """No teacher forcing: FPS + xyz kNN are exact, so the only divergence is rare feature-space
+    neighbour flips; the log-probabilities must still be close."""
+    from mpa_amd.models.repsurf.repsurf_ssg_umb import Model
+    g = golden_cls
+    args = Namespace(num_point=1024, return_dist=True, cuda_ops=False, num_class=40)
+    model = fill_state(Model(args), seed=0).cuda().eval()
+    torch.manual_seed(2024)
+    with torch.no_grad():
+        out = model(G(g["points"]))
+    close(out, g["out_eval"], tol=5e-3, what="cls eval log-probs (unforced)")
+
+
+def test_seg_model(P, golden_seg):
+    from mpa_amd.models.repsurf.pointnet2_part_seg_msg import get_model
+    g = golden_seg
+    model = fill_state(get_model(50), seed=0).cuda()
+    model.drop1.p = 0.0
+    pts, lab = G(g["points"]), G(g["label"])
+    model.eval()
+    with torch.no_grad():
+        out, forced = _run_model(g, model, lambda m: m(pts, lab)[0], [P], "")
+    print("seg eval: kNN rows differing before forcing: %d / %d" % (forced.flips, forced.total))
+    close(out, g["out_eval"], what="seg eval logits")
+    model.train()
+    out, forced = _run_model(g, model, lambda m: m(pts, lab)[0], [P], "train_")
+    close(out, g["out_train"], what="seg train logits")
+    (out * randn(out.shape, seed=31337).cuda()).sum().backward()
+    _check_grads(g, model)

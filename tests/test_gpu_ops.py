@@ -1,0 +1,184 @@
+"""GPU parity tests of the L0 point-set ops: HIP kernels (through the C ABI, via mpa_amd.ops)
+against (a) golden vectors produced by the reference itself and (b) the C oracle on seeded
+inputs.  Index results must be bit-exact; distances bitwise equal."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import bits
+from param_fill import unit_cloud, randn
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import mpa_amd
+    assert torch.cuda.is_available(), "gpu tests need the MI355X"
+    return mpa_amd.ops
+
+
+@pytest.fixture(scope="module")
+def co():
+    from oracle import c_oracle
+    return c_oracle
+
+
+def G(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def GL(a):
+    return torch.from_numpy(np.ascontiguousarray(a).astype(np.int64)).cuda()
+
+
+# --------------------------------------------------------------------------- FPS
+@pytest.mark.parametrize("tag", ["fps_a", "fps_b", "fps_c", "fps_d"])
+def test_fps_golden(ops, golden_index, tag):
+    g = golden_index
+    S = g[tag + "/idx"].shape[1]
+    idx, sub = ops.farthest_point_sample(G(g[tag + "/xyz"]), S, start_idx=torch.from_numpy(g[tag + "/start"]),
+                                         return_xyz=True)
+    assert np.array_equal(idx.cpu().numpy(), g[tag + "/idx"].astype(np.int64))
+    ref_sub = np.take_along_axis(g[tag + "/xyz"], g[tag + "/idx"].astype(np.int64)[..., None], axis=1)
+    assert np.array_equal(sub.cpu().numpy(), ref_sub)
+
+
+def test_fps_chain_golden(ops, golden_index):
+    g = golden_index
+    cur = G(g["fps_chain/xyz"])
+    for lvl, S in enumerate((512, 256, 128, 64, 32)):
+        idx, cur = ops.farthest_point_sample(cur, S, start_idx=torch.from_numpy(g["fps_chain/start%d" % lvl]),
+                                             return_xyz=True)
+        assert np.array_equal(idx.cpu().numpy(), g["fps_chain/idx%d" % lvl].astype(np.int64)), lvl
+
+
+def test_fps_seeded_like_reference(ops, golden_index):
+    """Same torch.manual_seed => same start indices as the reference draws them (CPU generator)."""
+    g = golden_index
+    torch.manual_seed(1024 + 512)
+    idx = ops.farthest_point_sample(G(g["fps_a/xyz"]), 512)
+    assert np.array_equal(idx.cpu().numpy(), g["fps_a/idx"].astype(np.int64))
+
+
+@pytest.mark.parametrize("B,N,S", [(3, 64, 64), (2, 65, 10), (5, 130, 77), (2, 300, 150), (2, 777, 256),
+                                   (2, 1500, 300), (1, 3000, 500), (1, 8192, 128), (7, 1, 1)])
+def test_fps_vs_oracle(ops, co, B, N, S):
+    xyz = unit_cloud(B, N, seed=N * 3 + S) if N > 1 else torch.zeros(B, 1, 3)
+    start = torch.randint(0, N, (B,), generator=torch.Generator().manual_seed(N))
+    got = ops.farthest_point_sample(xyz.cuda(), S, start_idx=start).cpu().numpy()
+    assert np.array_equal(got, co.farthest_point_sample(xyz.numpy(), S, start.numpy()))
+
+
+def test_fps_duplicates_first_max(ops, co):
+    """Duplicate points: once all distances are 0 the reference's argmax returns index 0."""
+    xyz = unit_cloud(2, 40, seed=9).repeat(1, 3, 1).contiguous()       # every point three times
+    start = torch.tensor([5, 77])
+    got = ops.farthest_point_sample(xyz.cuda(), 100, start_idx=start).cpu().numpy()
+    assert np.array_equal(got, co.farthest_point_sample(xyz.numpy(), 100, start.numpy()))
+
+
+def test_fps_full_size_properties(ops):
+    """BASELINE config size (B=64, N=1024 -> 512): samples are distinct and start where told."""
+    xyz = unit_cloud(64, 1024, seed=1234).cuda()
+    start = torch.arange(64) * 7
+    idx = ops.farthest_point_sample(xyz, 512, start_idx=start)
+    assert (idx[:, 0].cpu() == start).all()
+    s = idx.sort(dim=1)[0]
+    assert (s[:, 1:] != s[:, :-1]).all()
+    assert int(idx.min()) >= 0 and int(idx.max()) < 1024
+
+
+# --------------------------------------------------------------------------- kNN
+@pytest.mark.parametrize("tag", ["knn_a", "knn_b", "knn_c", "knn_d", "knn_e", "knn_f", "knn_g", "knn_h"])
+def test_knn_golden(ops, golden_index, tag):
+    g = golden_index
+    dist, idx = ops.knn_point(8, G(g[tag + "/base"]), G(g[tag + "/query"]))
+    assert np.array_equal(idx.cpu().numpy(), g[tag + "/idx"].astype(np.int64))
+    assert np.array_equal(bits(dist.cpu().numpy()), bits(g[tag + "/dist"]))
+
+
+@pytest.mark.parametrize("B,S,N,C,K", [(2, 70, 100, 3, 8), (1, 64, 64, 3, 3), (2, 1, 9, 3, 9), (2, 200, 300, 3, 16),
+                                       (1, 33, 400, 3, 32), (2, 100, 200, 16, 8), (2, 90, 150, 32, 8),
+                                       (1, 65, 130, 8, 4), (2, 40, 300, 64, 3), (1, 64, 96, 128, 16),
+                                       (1, 20, 50, 256, 8), (1, 30, 70, 512, 8), (2, 17, 23, 5, 2)])
+def test_knn_vs_oracle(ops, co, B, S, N, C, K):
+    base = unit_cloud(B, N, seed=S + N) if C == 3 else randn((B, N, C), seed=S * N + C)
+    query = randn((B, S, C), seed=C + 17, scale=0.5)
+    dist, idx = ops.knn_point(K, base.cuda(), query.cuda())
+    od, oi = co.knn_point(K, base.numpy(), query.numpy())
+    assert np.array_equal(idx.cpu().numpy(), oi)
+    assert np.array_equal(bits(dist.cpu().numpy()), bits(od))
+
+
+def test_knn_ties_lowest_index_first(ops):
+    base = torch.zeros(1, 16, 3).cuda()
+    _, idx = ops.knn_point(8, base, base[:, :4].contiguous())
+    assert (idx[0, 0].cpu() == torch.arange(8)).all()
+
+
+def test_knn_full_size_properties(ops):
+    """B=64, (S,N)=(512,1024): ascending distances, in-range distinct indices, and the query
+    (a member of the base set) finds itself first."""
+    xyz = unit_cloud(64, 1024, seed=1234).cuda()
+    q = xyz[:, ::2].contiguous()
+    dist, idx = ops.knn_point(8, xyz, q)
+    assert (dist[:, :, 1:] >= dist[:, :, :-1]).all()
+    assert int(idx.min()) >= 0 and int(idx.max()) < 1024
+    assert (idx[:, :, 0] == (torch.arange(512, device="cuda") * 2)).all()
+    s = idx.sort(dim=2)[0]
+    assert (s[:, :, 1:] != s[:, :, :-1]).all()
+
+
+def test_square_distance_golden(ops, golden_index):
+    g = golden_index
+    out = ops.square_distance(G(g["sqd/src"]), G(g["sqd/dst"]))
+    assert np.array_equal(bits(out.cpu().numpy()), bits(g["sqd/out"]))
+
+
+@pytest.mark.parametrize("tag", ["ball_a", "ball_b", "ball_c"])
+def test_ball_query_golden(ops, golden_index, tag):
+    g = golden_index
+    idx = ops.query_ball_point(float(g[tag + "/radius"]), 24, G(g[tag + "/base"]), G(g[tag + "/query"]))
+    assert np.array_equal(idx.cpu().numpy(), g[tag + "/idx"].astype(np.int64))
+
+
+def test_ball_query_no_hit_rows(ops, co):
+    base = unit_cloud(1, 50, seed=3)
+    query = base[:, :10] + 10.0          # far away: no hit, rows are filled with N
+    got = ops.query_ball_point(0.1, 6, base.cuda(), query.contiguous().cuda()).cpu().numpy()
+    assert np.array_equal(got, co.query_ball_point(0.1, 6, base.numpy(), query.numpy()))
+    assert (got == 50).all()
+
+
+def test_three_nn_golden(ops, golden_index):
+    g = golden_index
+    dist, idx = ops.three_nn(G(g["nn3/xyz1"]), G(g["nn3/xyz2"]))
+    assert np.array_equal(idx.cpu().numpy(), g["nn3/idx"].astype(np.int64))
+    assert np.array_equal(bits(dist.cpu().numpy()), bits(g["nn3/dist"]))
+
+
+# --------------------------------------------------------------------------- gathers
+@pytest.mark.parametrize("C", [3, 64, 10])
+def test_index_points_fwd_bwd(ops, C):
+    B, N, S, K = 3, 50, 20, 8
+    pts = randn((B, N, C), seed=C).cuda().requires_grad_(True)
+    idx = torch.randint(0, N, (B, S, K), generator=torch.Generator().manual_seed(1)).cuda()
+    out = ops.index_points(pts, idx)
+    ref = pts.detach()[torch.arange(B, device="cuda").view(B, 1, 1), idx]
+    assert torch.equal(out.detach(), ref)
+    g = randn(out.shape, seed=2).cuda()
+    out.backward(g)
+    want = torch.zeros(B, N, C, device="cuda")
+    want.view(B * N, C).index_add_(0, (idx + torch.arange(B, device="cuda").view(B, 1, 1) * N).view(-1),
+                                    g.view(-1, C))
+    assert (pts.grad - want).abs().max() < 1e-5
+    out2 = ops.index_points(pts, idx[:, :, 0])
+    assert torch.equal(out2.detach(), ref[:, :, 0])
+
+
+def test_ops_reject_cpu_tensors(ops):
+    with pytest.raises(RuntimeError):
+        ops.knn_point(8, torch.zeros(1, 16, 3), torch.zeros(1, 4, 3))
+    with pytest.raises(RuntimeError):
+        ops.farthest_point_sample(torch.zeros(1, 16, 3), 4)
