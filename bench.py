@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="clouds per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="launch every kernel from Python (no HIP graph)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -107,6 +108,7 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
+    local = local % torch.cuda.device_count()      # (rehearsals may stack ranks on one card)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -116,26 +118,35 @@ def main():
     from mpa_amd.models.repsurf.repsurf_ssg_umb import Model, SmoothClsLoss
 
     if world > 1:
-        mdist.init_process_group()
+        mdist.init_process_group(os.environ.get("MPA_DIST_BACKEND"))
     torch.manual_seed(0)
     args = argparse.Namespace(num_point=NUM_POINT, return_dist=True, cuda_ops=True, num_class=NUM_CLASS)
     model = Model(args).to(dev).train()
-    reducer = mdist.GradReducer(model) if world > 1 else None
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
     crit = SmoothClsLoss()
     x, y = synthetic_batch(a.batch, 1234 + rank, dev)
+    if a.eager:
+        reducer = mdist.GradReducer(model) if world > 1 else None
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
 
-    def step():
-        if reducer is not None:
-            reducer.zero_grad()
-        else:
-            opt.zero_grad(set_to_none=True)
-        loss = crit(model(x), y)
-        loss.backward()
-        if reducer is not None:
-            reducer.all_reduce()
-        opt.step()
-        return loss
+        def step():
+            if reducer is not None:
+                reducer.zero_grad()
+            else:
+                opt.zero_grad(set_to_none=True)
+            loss = crit(model(x), y)
+            loss.backward()
+            if reducer is not None:
+                reducer.all_reduce()
+            opt.step()
+            return loss
+    else:
+        # the whole forward+backward is one HIP graph; all-reduce + (graphed) Adam follow it
+        from mpa_amd.runtime import GraphedTrainStep
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True)
+        graphed = GraphedTrainStep(model, crit, opt, (x, y))
+
+        def step():
+            return graphed(x, y)
 
     for _ in range(a.warmup):
         step()
@@ -174,7 +185,7 @@ def main():
             "config": {"workload": "ModelNet40-shaped classification, 1024 points, batch %d per GPU, fp32, "
                                    "fwd+loss+bwd+Adam (BASELINE configs[1])" % a.batch,
                        "points": NUM_POINT, "batch_per_gpu": a.batch, "global_batch": a.batch * world,
-                       "parallelism": "dp%d" % world},
+                       "parallelism": "dp%d" % world, "launch": "eager" if a.eager else "hipgraph"},
             "roofline": roof,
         }
         if world == 1 and not a.no_cpu_baseline:

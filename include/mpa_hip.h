@@ -21,6 +21,7 @@
 #ifndef MPA_HIP_H
 #define MPA_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -108,6 +109,48 @@ int mpa_diffattn_xyz_bwd_f32(const float *xyz, const float *center, const int64_
                              const float *grad_ctx, int B, int N, int S, int K, int C,
                              float *gWq, float *gbq, float *gWk, float *gbk, float *gWv, float *gbv,
                              void *stream);
+
+/* ---- Linear: the transition / pointwise MLP unit, modules/pointnet2_utils.py:401-425
+ * (nn.Linear -> BatchNorm1d over the B*S rows -> LeakyReLU(0.2)).
+ * GEMMs run on fp32 MFMA (v_mfma_f32_32x32x2_f32: bit-equal to an fmaf chain over k).
+ *   mpa_gemm_f32:  C[M,N] = op(A) * op(B) (+ bias[N]) (+ C if accumulate)
+ *       transA = 0: A is [M,K] (lda);  transA = 1: A is stored [K,M] (lda)
+ *       transB = 0: B is [K,N] (ldb);  transB = 1: B is stored [N,K] (ldb)  (nn.Linear.weight)
+ *   tile_stats (optional): [ceil(M/64)][2][N] floats, fully written by the epilogue: for every
+ *   64-row tile and column the sum and the sum of squared deviations from the tile mean -- the
+ *   BatchNorm batch statistics in Chan's pairwise form (no atomics: deterministic; no
+ *   E[y^2]-E[y]^2 cancellation).  mpa_bn_finalize_f32 combines them.
+ *   workspace (optional, 16-B aligned): scratch for split-K partial tiles (weight gradients have
+ *   K = B*S rows and a tiny output); without it split-K falls back to float atomics into C.
+ *   accumulate != 0 adds into C. */
+int mpa_gemm_f32(const float *A, int lda, int transA, const float *B, int ldb, int transB,
+                 const float *bias, float *C, int ldc, int M, int N, int K, int accumulate,
+                 float *tile_stats, float *workspace, size_t workspace_bytes, void *stream);
+/* tile statistics (same format as the GEMM epilogue's) of an existing tensor x [M,C]. */
+int mpa_tile_stats_f32(const float *x, int M, int C, float *tile_stats, void *stream);
+/* per-column sum and sum of squares of x [M,C] -> col_sum, col_sumsq [C] (caller zeroes). */
+int mpa_col_stats_f32(const float *x, int M, int C, float *col_sum, float *col_sumsq, void *stream);
+/* BatchNorm1d statistics: save_mean_invstd [2][C] <- (mean, 1/sqrt(var+eps)).  training != 0:
+ * from tile_stats over the M rows (biased variance), and running_mean/var (may be NULL) are
+ * updated with `momentum` (unbiased variance) as nn.BatchNorm1d does; training == 0: from the
+ * running statistics (tile_stats ignored). */
+int mpa_bn_finalize_f32(const float *tile_stats, int M, int C, float *running_mean, float *running_var,
+                        int training, float momentum, float eps, float *save_mean_invstd, void *stream);
+/* y = leaky_relu((x - mean[c]) * invstd[c] * gamma[c] + beta[c], slope) over [M,C]  (slope = 1:
+ * no activation).  In place allowed (y == x). */
+int mpa_bn_act_fwd_f32(const float *x, const float *save_mean_invstd, const float *gamma, const float *beta,
+                       float slope, int M, int C, float *y, void *stream);
+/* backward of y = lrelu(bn(x)): pass 1 accumulates (caller zeroes) sum_g[c] = sum g and
+ * sum_gxhat[c] = sum g*xhat with g = grad_y * lrelu'(.)  (these are dbeta and dgamma);
+ * pass 2 writes grad_x = gamma*invstd*(g - sum_g/M - xhat*sum_gxhat/M) (use_batch_stats != 0)
+ * or gamma*invstd*g (running statistics). */
+int mpa_bn_act_bwd_reduce_f32(const float *x, const float *grad_y, const float *mean, const float *invstd,
+                              const float *gamma, const float *beta, float slope, int M, int C,
+                              float *sum_g, float *sum_gxhat, void *stream);
+int mpa_bn_act_bwd_apply_f32(const float *x, const float *grad_y, const float *mean, const float *invstd,
+                             const float *gamma, const float *beta, const float *sum_g,
+                             const float *sum_gxhat, float slope, int use_batch_stats, int M, int C,
+                             float *grad_x, void *stream);
 
 /* ---- upsample: the decoder's coarse->fine transition, modules/pointnet2_utils.py:13-50.
  * points [B,S,C], knn_idx [B,S,K] with values < Nf (= S*scale_ratio).  out [B,Nf,C] is the

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(TPB) void diffattn_fwd_kernel(const float *__restri
 #pragma unroll
         for (int j = 0; j < (K_ > 0 ? K_ : KMAX); ++j)
             if (j < k_) {
-                long long row = ((long long)b * N + nb[j]) * ldkv + c;
+                long long row = ((long long)b * N + mpa_clamp_idx(nb[j], N)) * ldkv + c;
                 e[j] = (qv - kk[row]) * alpha;
                 v[j] = vv[row];
             }
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(TPB) void diffattn_bwd_kernel(const float *__restri
 #pragma unroll
         for (int j = 0; j < (K_ > 0 ? K_ : KMAX); ++j)
             if (j < k_) {
-                long long r = (long long)b * N + nb[j];
+                long long r = (long long)b * N + mpa_clamp_idx(nb[j], N);
                 rows[j] = r;
                 e[j] = (qv - kk[r * ldkv + c]) * alpha;
                 if (j == ks) { vstar = vv[r * ldkv + c]; rstar = r; }
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(TPB) void diffattn_xyz_fwd_kernel(
 #pragma unroll
         for (int j = 0; j < (K_ > 0 ? K_ : KMAX); ++j)
             if (j < k_) {
-                const float *x = xyz + ((long long)b * N + nb[j]) * 3;
+                const float *x = xyz + ((long long)b * N + mpa_clamp_idx(nb[j], N)) * 3;
                 float rx = x[0] - cx, ry = x[1] - cy, rz = x[2] - cz;
                 float kj = fmaf(wk2, rz, fmaf(wk1, ry, fmaf(wk0, rx, bkc)));
                 v[j] = fmaf(wv2, rz, fmaf(wv1, ry, fmaf(wv0, rx, bvc)));
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(TPB) void diffattn_xyz_bwd_kernel(
 #pragma unroll
         for (int j = 0; j < (K_ > 0 ? K_ : KMAX); ++j)
             if (j < k_) {
-                const float *x = xyz + ((long long)b * N + nb[j]) * 3;
+                const float *x = xyz + ((long long)b * N + mpa_clamp_idx(nb[j], N)) * 3;
                 rx[j] = x[0] - cx; ry[j] = x[1] - cy; rz[j] = x[2] - cz;
                 float kj = fmaf(wk2, rz[j], fmaf(wk1, ry[j], fmaf(wk0, rx[j], bkc)));
                 e[j] = (qv - kj) * alpha;

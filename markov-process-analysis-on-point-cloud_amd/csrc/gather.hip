@@ -20,7 +20,7 @@ __global__ void gather_fwd_kernel(const float *__restrict__ points, const int64_
         long long row = i / CV;
         int c = (int)(i - row * CV);
         int b = (int)(row / M);
-        long long src = (long long)b * N + idx[row];
+        long long src = (long long)b * N + mpa_clamp_idx(idx[row], N);
         reinterpret_cast<V *>(out)[i] = reinterpret_cast<const V *>(points)[src * CV + c];
     }
 }
@@ -34,7 +34,7 @@ __global__ void gather_bwd_kernel(const float *__restrict__ grad_out, const int6
         long long row = i / C;
         int c = (int)(i - row * C);
         int b = (int)(row / M);
-        long long dst = (long long)b * N + idx[row];
+        long long dst = (long long)b * N + mpa_clamp_idx(idx[row], N);
         atomicAdd(grad_points + dst * C + c, grad_out[i]);
     }
 }
@@ -54,9 +54,9 @@ __global__ void upsample_scatter_kernel(const float *__restrict__ points, const 
         int k = (int)(e - bs * K);
         int b = (int)(bs / S);
         const int64_t *row = knn + bs * K;
-        int64_t n = row[k];
+        int64_t n = mpa_clamp_idx(row[k], Nf);
         bool dup = false;
-        for (int j = 0; j < k; ++j) dup |= (row[j] == n);
+        for (int j = 0; j < k; ++j) dup |= (mpa_clamp_idx(row[j], Nf) == n);
         if (dup) continue;
         float p = points[bs * C + c];
         long long dst = (long long)b * Nf + n;
@@ -88,9 +88,9 @@ __global__ void upsample_bwd_kernel(const float *__restrict__ grad_out, const in
         const int64_t *row = knn + bs * K;
         float acc = 0.f;
         for (int k = 0; k < K; ++k) {
-            int64_t n = row[k];
+            int64_t n = mpa_clamp_idx(row[k], Nf);
             bool dup = false;
-            for (int j = 0; j < k; ++j) dup |= (row[j] == n);
+            for (int j = 0; j < k; ++j) dup |= (mpa_clamp_idx(row[j], Nf) == n);
             if (dup) continue;
             long long src = (long long)b * Nf + n;
             float d = cnt[src];
@@ -121,9 +121,9 @@ __global__ void interp_fwd_kernel(const float *__restrict__ points2, const int64
         interp_weights(dist + row * 3, w);
         const int64_t *id = idx + row * 3;
         const float *p = points2 + (long long)b * Nb * C + c;
-        float acc = p[id[0] * C] * w[0];
-        acc += p[id[1] * C] * w[1];
-        acc += p[id[2] * C] * w[2];
+        float acc = p[mpa_clamp_idx(id[0], Nb) * C] * w[0];
+        acc += p[mpa_clamp_idx(id[1], Nb) * C] * w[1];
+        acc += p[mpa_clamp_idx(id[2], Nb) * C] * w[2];
         out[i] = acc;
     }
 }
@@ -142,9 +142,9 @@ __global__ void interp_bwd_kernel(const float *__restrict__ grad_out, const int6
         const int64_t *id = idx + row * 3;
         float *p = grad_points2 + (long long)b * Nb * C + c;
         float g = grad_out[i];
-        atomicAdd(p + id[0] * C, g * w[0]);
-        atomicAdd(p + id[1] * C, g * w[1]);
-        atomicAdd(p + id[2] * C, g * w[2]);
+        atomicAdd(p + mpa_clamp_idx(id[0], Nb) * C, g * w[0]);
+        atomicAdd(p + mpa_clamp_idx(id[1], Nb) * C, g * w[1]);
+        atomicAdd(p + mpa_clamp_idx(id[2], Nb) * C, g * w[2]);
     }
 }
 

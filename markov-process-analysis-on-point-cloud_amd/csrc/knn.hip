@@ -184,7 +184,7 @@ __global__ __launch_bounds__(TQ) void knn_kernel(const float *__restrict__ base,
     float bd[KMAX];
     int bi[KMAX];
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k) { bd[k] = INFINITY; bi[k] = -1; }
+    for (int k = 0; k < KMAX; ++k) { bd[k] = INFINITY; bi[k] = 0; }   // NaN inputs: in-range garbage, never -1
 
     for (int n0 = 0; n0 < N; n0 += TB) {
         const int rows = min(TB, N - n0);

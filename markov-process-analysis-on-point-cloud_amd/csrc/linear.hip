@@ -1,0 +1,737 @@
+// The transition / pointwise MLP unit for gfx950 -- reference Linear
+// (modules/pointnet2_utils.py:401-425): nn.Linear -> BatchNorm1d over the B*S rows -> LeakyReLU.
+//
+// GEMM: LDS-tiled fp32 MFMA (v_mfma_f32_32x32x2_f32).  The f32 MFMA is bit-equal to an fmaf
+// chain over k, so results do not depend on the tiling.  Both LDS tiles are kept k-major
+// ([k][m] and [k][n]): a lane's MFMA operand is then As[k0 + (lane>>5)][m0 + (lane&31)], i.e.
+// each half-wave reads 32 consecutive floats -- conflict-free ds_read_b32.  Row-major operands
+// (activations [M,K], nn.Linear weights [N,K]) are transposed while being staged; k-major
+// operands (dY^T, X in the weight-gradient product) are staged with straight float4 copies.
+// The epilogue adds the bias, optionally accumulates with float atomics (split-K weight
+// gradients) and optionally produces the per-column sum / sum of squares that BatchNorm needs,
+// so the activation tensor is not re-read for statistics.
+//
+// Most layers here are K,N in {64,128}: arithmetic intensity ~16 FLOP/B against a machine
+// balance of ~25, i.e. HBM-bound; the wide layers (512..2048) are MFMA-bound.
+#include "mpa_common.h"
+#include <cstdlib>
+
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int NT = 256;   // threads per workgroup (4 waves)
+constexpr int TS = 64;    // output tile: 64 x 64 per workgroup
+constexpr int KS = 64;    // K slab staged per iteration; each of the 4 waves owns 16 of its k
+
+// One workgroup = one 64x64 output tile, its 4 waves splitting K ("intra-block split-K"):
+// every wave holds the whole tile in 4 MFMA accumulators (64 AGPRs) and consumes its own
+// quarter of each 64-deep K slab, so the LDS operand reads are 4 ds_read_b32 per 4 MFMAs
+// (256 MFMA cycles) and the small outputs of this model (M*N/4096 tiles) still put 4 waves on
+// every CU.  Slabs are double-buffered in LDS with the next slab's global loads issued before
+// the current slab's MFMAs (one barrier per slab).  The four partial tiles are summed through
+// LDS, which also turns the epilogue into coalesced float4 row stores with the bias, the
+// BatchNorm column statistics and (for split-K across workgroups) float atomics.
+template <bool TA, bool TB>
+__global__ __launch_bounds__(NT, 2) void gemm_kernel(const float *__restrict__ A, int lda,
+                                                     const float *__restrict__ B, int ldb,
+                                                     const float *__restrict__ bias, float *__restrict__ C, int ldc,
+                                                     int M, int N, int K, int kchunk, int out_mode, int vecA,
+                                                     int vecB, float *__restrict__ tile_stats)
+{
+    // out_mode 0: C = result (+bias);  1: atomicAdd into C;  2: split-K partial slab
+    //             C + blockIdx.z*M*ldc (plain stores, summed by splitk_reduce_kernel).
+    // tile_stats [tiles_m][2][N] (optional): per 64-row tile and column, the sum and the sum of
+    // squared deviations from the TILE mean (Chan's pairwise form).  Plain stores, no atomics:
+    // BatchNorm statistics stay deterministic, and mpa_bn_finalize_f32 combines the tiles without
+    // the catastrophic cancellation of E[y^2] - E[y]^2.
+    // k-major LDS tiles [k][m] / [k][n], unpadded (2 x 2 x 16 KiB = exactly 64 KiB, so no
+    // large-LDS opt-in is needed and two workgroups fit a CU).  Row-major global operands are
+    // transposed while staged (4 strided ds_write_b32 per float4); the column index is XOR-swizzled
+    // with SWZ(k) = 4*((k>>2)&7) so those writes spread over the banks (2-way at worst) while a
+    // half-wave's MFMA operand read (32 consecutive columns of one k row) stays a permutation of
+    // 32 banks.  k-major operands are copied with ds_write_b128 (the swizzle is a multiple of 4).
+    constexpr int LDA = TS, LDB = TS;
+    constexpr int BUF = KS * (LDA + LDB);
+    extern __shared__ float lds[];   // 2 * BUF floats = 4*64*64: reused by the final reduction
+#define SWZ(k) ((((k) >> 2) & 7) << 2)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+
+    // XCD-aware tile order: consecutive workgroups are dealt round-robin to the 8 XCDs, so give
+    // each XCD a contiguous run of tiles (tiles sharing A rows / B columns then share an L2).
+    const int tiles_n = (N + TS - 1) / TS, tiles_m = (M + TS - 1) / TS;
+    const int ntiles = tiles_m * tiles_n;
+    int id = blockIdx.x;
+    if ((ntiles & 7) == 0) id = (id & 7) * (ntiles >> 3) + (id >> 3);
+    const int m0 = (id / tiles_n) * TS, n0 = (id % tiles_n) * TS;
+    const int kbeg = blockIdx.z * kchunk;
+    const int kend = min(K, kbeg + kchunk);
+    const int nslab = (kend - kbeg + KS - 1) / KS;
+
+    float4 ra[4], rb[4];
+    // ---- global -> registers for slab s (64 x 64 floats per operand = 4 float4 per lane)
+    auto load_slab = [&](int s) {
+        const int k0 = kbeg + s * KS;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = tid + NT * q;
+            {   // A
+                int r, c;            // r: row of the global matrix walked by this lane, c: 4-wide column start
+                int gr, gc;
+                bool rok;
+                if (!TA) { r = i >> 4; c = (i & 15) * 4; gr = m0 + r; gc = k0 + c; rok = gr < M; }
+                else { r = i >> 4; c = (i & 15) * 4; gr = k0 + r; gc = m0 + c; rok = gr < kend; }
+                const int lim = TA ? M : kend;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (rok) {
+                    const float *p = A + (size_t)gr * lda + gc;
+                    if (vecA && gc + 3 < lim) v = *reinterpret_cast<const float4 *>(p);
+                    else {
+                        if (gc < lim) v.x = p[0];
+                        if (gc + 1 < lim) v.y = p[1];
+                        if (gc + 2 < lim) v.z = p[2];
+                        if (gc + 3 < lim) v.w = p[3];
+                    }
+                }
+                ra[q] = v;
+            }
+            {   // B
+                int r, c, gr, gc;
+                bool rok;
+                if (TB) { r = i >> 4; c = (i & 15) * 4; gr = n0 + r; gc = k0 + c; rok = gr < N; }
+                else { r = i >> 4; c = (i & 15) * 4; gr = k0 + r; gc = n0 + c; rok = gr < kend; }
+                const int lim = TB ? kend : N;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (rok) {
+                    const float *p = B + (size_t)gr * ldb + gc;
+                    if (vecB && gc + 3 < lim) v = *reinterpret_cast<const float4 *>(p);
+                    else {
+                        if (gc < lim) v.x = p[0];
+                        if (gc + 1 < lim) v.y = p[1];
+                        if (gc + 2 < lim) v.z = p[2];
+                        if (gc + 3 < lim) v.w = p[3];
+                    }
+                }
+                rb[q] = v;
+            }
+        }
+    };
+    // ---- registers -> LDS buffer
+    auto store_slab = [&](float *buf) {
+        float *As = buf, *Bs = buf + KS * LDA;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = tid + NT * q;
+            const int r = i >> 4, c = (i & 15) * 4;
+            if (!TA) {            // lane holds A[m = r][k = c..c+3] -> As[k][m ^ SWZ(k)]  (SWZ(c..c+3) equal)
+                float *d = As + c * LDA + (r ^ SWZ(c));
+                d[0] = ra[q].x; d[LDA] = ra[q].y; d[2 * LDA] = ra[q].z; d[3 * LDA] = ra[q].w;
+            } else {              // lane holds A^T[k = r][m = c..c+3]
+                *reinterpret_cast<float4 *>(As + r * LDA + (c ^ SWZ(r))) = ra[q];
+            }
+            if (TB) {             // lane holds B[n = r][k = c..c+3] -> Bs[k][n ^ SWZ(k)]
+                float *d = Bs + c * LDB + (r ^ SWZ(c));
+                d[0] = rb[q].x; d[LDB] = rb[q].y; d[2 * LDB] = rb[q].z; d[3 * LDB] = rb[q].w;
+            } else {
+                *reinterpret_cast<float4 *>(Bs + r * LDB + (c ^ SWZ(r))) = rb[q];
+            }
+        }
+    };
+
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (nslab > 0) {
+        load_slab(0);
+        store_slab(lds);
+    }
+    __syncthreads();
+    for (int s = 0; s < nslab; ++s) {
+        float *buf = lds + (s & 1) * BUF;
+        if (s + 1 < nslab) load_slab(s + 1);          // in flight during this slab's MFMAs
+        const float *As = buf + (wave * 16 + half) * LDA;
+        const float *Bs = buf + KS * LDA + (wave * 16 + half) * LDB;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            // k = wave*16 + 2t + half: (k>>2)&7 = (wave*4 + (t>>1)) & 7, the same for both halves
+            const int cs = l31 ^ ((((wave << 2) + (t >> 1)) & 7) << 2);
+            const float a0 = As[2 * t * LDA + cs], a1 = As[2 * t * LDA + 32 + cs];
+            const float b0 = Bs[2 * t * LDB + cs], b1 = Bs[2 * t * LDB + 32 + cs];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (s + 1 < nslab) store_slab(lds + ((s + 1) & 1) * BUF);
+        __syncthreads();
+    }
+
+    // ---- sum the 4 waves' partial tiles through LDS: red[wave][row][col], 64 x 64 each
+    float *red = lds + wave * (TS * TS);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                red[row * TS + j * 32 + l31] = acc[i][j][r];
+            }
+    __syncthreads();
+
+    if (out_mode == 1) {
+        // float atomics want 256 contiguous bytes per wave instruction: lane = column
+        const int cl = tid & 63, colA = n0 + cl;
+        const float bA = (bias != nullptr && blockIdx.z == 0 && colA < N) ? bias[colA] : 0.f;
+#pragma unroll 4
+        for (int q = 0; q < 16; ++q) {
+            const int rloc = (tid >> 6) + 4 * q;
+            const float *p = lds + rloc * TS + cl;
+            const float v = ((p[0] + p[TS * TS]) + (p[2 * TS * TS] + p[3 * TS * TS])) + bA;
+            if (m0 + rloc < M && colA < N) atomicAdd(C + (size_t)(m0 + rloc) * ldc + colA, v);
+        }
+        return;
+    }
+    if (out_mode == 2) C += (size_t)blockIdx.z * M * ldc;
+
+    const int c4 = (tid & 15) * 4;            // this lane's 4 columns (same for its 4 rows)
+    const int col = n0 + c4;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias != nullptr && blockIdx.z == 0) {
+        if (col < N) bv.x = bias[col];
+        if (col + 1 < N) bv.y = bias[col + 1];
+        if (col + 2 < N) bv.z = bias[col + 2];
+        if (col + 3 < N) bv.w = bias[col + 3];
+    }
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 vkeep[4];
+    const bool vecC = ((ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int rloc = (tid >> 4) + 16 * q;
+        const int row = m0 + rloc;
+        const float *p = lds + rloc * TS + c4;
+        float4 v = *reinterpret_cast<const float4 *>(p);
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const float4 u = *reinterpret_cast<const float4 *>(p + w * TS * TS);
+            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        }
+        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+        vkeep[q] = v;
+        if (row < M) {
+            float *o = C + (size_t)row * ldc + col;
+            if (vecC && col + 3 < N) {
+                *reinterpret_cast<float4 *>(o) = v;
+            } else {
+                if (col < N) o[0] = v.x;
+                if (col + 1 < N) o[1] = v.y;
+                if (col + 2 < N) o[2] = v.z;
+                if (col + 3 < N) o[3] = v.w;
+            }
+            s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+        }
+    }
+    if (tile_stats != nullptr) {
+        // column sums over the tile's rows: lanes t, t+16, t+32, t+48 of a wave share the columns,
+        // then the 4 waves through LDS; the tile mean goes back to every lane for the second pass
+        const int tile_m = id / tiles_n;
+        const int nrows = min(TS, M - m0);
+        float *st = lds;                       // [4 waves][64] scratch, then [64] tile means
+        float vs[4] = {s1.x, s1.y, s1.z, s1.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            vs[e] += __shfl_xor(vs[e], 16, 64);
+            vs[e] += __shfl_xor(vs[e], 32, 64);
+        }
+        __syncthreads();                       // everyone is done reading the partial tiles
+        if (lane < 16) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) st[wave * TS + c4 + e] = vs[e];
+        }
+        __syncthreads();
+        float tsum = 0.f;
+        if (tid < TS) {
+            tsum = (st[tid] + st[TS + tid]) + (st[2 * TS + tid] + st[3 * TS + tid]);
+            st[4 * TS + tid] = tsum / (float)nrows;
+        }
+        __syncthreads();
+        const float4 mu = *reinterpret_cast<const float4 *>(st + 4 * TS + c4);
+        float4 d2 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (m0 + (tid >> 4) + 16 * q < M) {
+                float dx = vkeep[q].x - mu.x, dy = vkeep[q].y - mu.y, dz = vkeep[q].z - mu.z, dw = vkeep[q].w - mu.w;
+                d2.x = fmaf(dx, dx, d2.x); d2.y = fmaf(dy, dy, d2.y);
+                d2.z = fmaf(dz, dz, d2.z); d2.w = fmaf(dw, dw, d2.w);
+            }
+        }
+        float vq[4] = {d2.x, d2.y, d2.z, d2.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            vq[e] += __shfl_xor(vq[e], 16, 64);
+            vq[e] += __shfl_xor(vq[e], 32, 64);
+        }
+        if (lane < 16) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) st[(5 + wave) * TS + c4 + e] = vq[e];
+        }
+        __syncthreads();
+        if (tid < TS && n0 + tid < N) {
+            const float m2 = (st[5 * TS + tid] + st[6 * TS + tid]) + (st[7 * TS + tid] + st[8 * TS + tid]);
+            float *dst = tile_stats + (size_t)tile_m * 2 * N + n0 + tid;
+            dst[0] = tsum;
+            dst[N] = m2;
+        }
+    }
+}
+
+constexpr size_t gemm_lds_bytes(bool, bool) { return sizeof(float) * 2 * KS * (TS + TS); }   // 64 KiB
+
+template <bool TA, bool TB>
+int launch_gemm(const float *A, int lda, const float *B, int ldb, const float *bias, float *C, int ldc, int M, int N,
+                int K, int splits, int kchunk, int out_mode, int vecA, int vecB, float *stats, hipStream_t st)
+{
+    constexpr size_t lds = gemm_lds_bytes(TA, TB);
+    static_assert(lds >= sizeof(float) * 4 * TS * TS && lds <= 64 * 1024, "reduction region fits, no opt-in");
+    dim3 grid(mpa_ceil_div(M, TS) * mpa_ceil_div(N, TS), 1, splits);
+    hipLaunchKernelGGL((gemm_kernel<TA, TB>), grid, dim3(NT), lds, st, A, lda, B, ldb, bias, C, ldc, M, N, K, kchunk,
+                       out_mode, vecA, vecB, stats);
+    return MPA_OK;
+}
+
+// out[M,N] += sum_z part[z][M,N]   (split-K partial slabs written with plain stores).
+// The sum over z is itself split over gridDim.y workgroups (a 64x64 weight gradient has 4096
+// outputs but hundreds of slabs), each adding its share with one float atomic per element: at
+// most gridDim.y (<= 32) adders per address.  `out` is zeroed by the caller unless accumulating.
+__global__ void splitk_reduce_kernel(const float *__restrict__ part, int splits, long long mn,
+                                     float *__restrict__ out)
+{
+    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (i >= mn) return;
+    const int zper = (splits + gridDim.y - 1) / gridDim.y;
+    const int z0 = blockIdx.y * zper, z1 = min(splits, z0 + zper);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int z = z0;
+    for (; z + 3 < z1; z += 4) {
+        a0 += part[(size_t)z * mn + i];
+        a1 += part[(size_t)(z + 1) * mn + i];
+        a2 += part[(size_t)(z + 2) * mn + i];
+        a3 += part[(size_t)(z + 3) * mn + i];
+    }
+    for (; z < z1; ++z) a0 += part[(size_t)z * mn + i];
+    if (z0 < z1) atomicAdd(out + i, (a0 + a1) + (a2 + a3));
+}
+
+// ------------------------------------------------------------------ BatchNorm + LeakyReLU pieces
+constexpr int EW_TPB = 256;
+
+// Per-tile statistics of an existing [M,C] tensor in the GEMM epilogue's format
+// (tile_stats [ceil(M/64)][2][C]: sum, sum of squared deviations from the tile mean).
+__global__ __launch_bounds__(256) void tile_stats_kernel(const float *__restrict__ x, int M, int C,
+                                                         float *__restrict__ tile_stats)
+{
+    __shared__ float red[4][64];
+    __shared__ float mean[64];
+    const int tid = threadIdx.x, cl = tid & 63, g = tid >> 6;
+    const int c = blockIdx.x * 64 + cl, r0 = blockIdx.y * TS;
+    const int nrows = min(TS, M - r0);
+    float v[16];
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int r = g + 4 * q;
+        v[q] = (r < nrows && c < C) ? x[(size_t)(r0 + r) * C + c] : 0.f;
+        s += v[q];
+    }
+    red[g][cl] = s;
+    __syncthreads();
+    if (g == 0) {
+        s = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+        mean[cl] = s / (float)nrows;
+    }
+    __syncthreads();
+    const float mu = mean[cl];
+    float m2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+        if (g + 4 * q < nrows) { const float d = v[q] - mu; m2 = fmaf(d, d, m2); }
+    __syncthreads();
+    red[g][cl] = m2;
+    __syncthreads();
+    if (g == 0 && c < C) {
+        float *dst = tile_stats + (size_t)blockIdx.y * 2 * C + c;
+        dst[0] = s;
+        dst[C] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+    }
+}
+
+// mean / invstd per channel.  Training: combine the tiles' (sum, M2) pairwise-exactly --
+// mean = sum(sum_t)/M, M2 = sum(M2_t + n_t*(sum_t/n_t - mean)^2), biased variance M2/M -- in a
+// fixed order (deterministic), and update the running statistics (momentum, unbiased variance)
+// as nn.BatchNorm1d does.  Eval: from the running statistics.  out = save [2][C] (mean, invstd).
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float *__restrict__ tile_stats, int M, int C,
+                                                          float *__restrict__ running_mean,
+                                                          float *__restrict__ running_var, int training,
+                                                          float momentum, float eps, float *__restrict__ save)
+{
+    __shared__ float red[4][64];
+    __shared__ float mean_s[64];
+    const int tid = threadIdx.x, cl = tid & 63, g = tid >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    if (!training) {
+        if (g == 0 && c < C) {
+            save[c] = running_mean[c];
+            save[C + c] = 1.0f / sqrtf(running_var[c] + eps);
+        }
+        return;
+    }
+    const int tiles = (M + TS - 1) / TS;
+    float s = 0.f;
+    if (c < C)
+        for (int t = g; t < tiles; t += 4) s += tile_stats[(size_t)t * 2 * C + c];
+    red[g][cl] = s;
+    __syncthreads();
+    if (g == 0) mean_s[cl] = ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) / (float)M;
+    __syncthreads();
+    const float mean = mean_s[cl];
+    float m2 = 0.f;
+    if (c < C)
+        for (int t = g; t < tiles; t += 4) {
+            const float nt = (float)min(TS, M - t * TS);
+            const float d = tile_stats[(size_t)t * 2 * C + c] / nt - mean;
+            m2 += tile_stats[(size_t)t * 2 * C + C + c] + nt * d * d;
+        }
+    __syncthreads();
+    red[g][cl] = m2;
+    __syncthreads();
+    if (g == 0 && c < C) {
+        const float var = ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) / (float)M;
+        save[c] = mean;
+        save[C + c] = 1.0f / sqrtf(var + eps);
+        if (running_mean) {
+            const float unb = M > 1 ? var * ((float)M / (float)(M - 1)) : var;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
+        }
+    }
+}
+
+// y = lrelu((x - mean[c]) * invstd[c] * gamma[c] + beta[c]); every workgroup stages the
+// per-channel scale/shift in LDS, then streams its share of the rows with float4 accesses.
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float *__restrict__ x, const float *__restrict__ save,
+                                                         const float *__restrict__ gamma,
+                                                         const float *__restrict__ beta, float slope, int M, int C,
+                                                         float *__restrict__ y)
+{
+    extern __shared__ float ss[];          // scale[C], shift[C]
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float sc = gamma[c] * save[C + c];
+        ss[c] = sc;
+        ss[C + c] = beta[c] - save[c] * sc;
+    }
+    __syncthreads();
+    if ((C & 3) == 0) {
+        const long long total4 = (long long)M * C / 4;
+        const int c4n = C / 4;
+        for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4;
+             i += (long long)gridDim.x * blockDim.x) {
+            const int c = (int)(i % c4n) * 4;
+            const float4 v = reinterpret_cast<const float4 *>(x)[i];
+            const float4 sc = *reinterpret_cast<const float4 *>(ss + c);
+            const float4 sh = *reinterpret_cast<const float4 *>(ss + C + c);
+            float4 o;
+            o.x = fmaf(v.x, sc.x, sh.x); o.y = fmaf(v.y, sc.y, sh.y);
+            o.z = fmaf(v.z, sc.z, sh.z); o.w = fmaf(v.w, sc.w, sh.w);
+            o.x = o.x > 0.f ? o.x : o.x * slope; o.y = o.y > 0.f ? o.y : o.y * slope;
+            o.z = o.z > 0.f ? o.z : o.z * slope; o.w = o.w > 0.f ? o.w : o.w * slope;
+            reinterpret_cast<float4 *>(y)[i] = o;
+        }
+    } else {
+        const long long total = (long long)M * C;
+        for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+             i += (long long)gridDim.x * blockDim.x) {
+            const int c = (int)(i % C);
+            const float t = fmaf(x[i], ss[c], ss[C + c]);
+            y[i] = t > 0.f ? t : t * slope;
+        }
+    }
+}
+
+// Column reductions over the M rows of an [M,C] tensor.  A workgroup owns a slab of rows and
+// a group of <= 256 channels; its 256 lanes are arranged [RY][CPB] (channel fastest: coalesced
+// rows), each lane walks its rows 4 at a time (independent loads in flight), the RY partials
+// are combined through LDS and one float atomic per (workgroup, channel) goes to HBM.
+template <typename F>
+__device__ __forceinline__ void slab_reduce2(int M, int C, int cpb, int rows_per_block, float *out0, float *out1, F f)
+{
+    __shared__ float red[2][256];
+    const int tid = threadIdx.x;
+    const int ry = tid / cpb, cl = tid - ry * cpb, RY = blockDim.x / cpb;
+    const int c = blockIdx.y * cpb + cl;
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(M, r0 + rows_per_block);
+    float a0 = 0.f, a1 = 0.f;
+    if (c < C && ry < RY) {
+        int r = r0 + ry;
+        for (; r + 3 * RY < r1; r += 4 * RY) {
+            float p0 = 0.f, p1 = 0.f, q0 = 0.f, q1 = 0.f, s0 = 0.f, s1 = 0.f, t0 = 0.f, t1 = 0.f;
+            f(r, c, p0, p1); f(r + RY, c, q0, q1); f(r + 2 * RY, c, s0, s1); f(r + 3 * RY, c, t0, t1);
+            a0 += (p0 + q0) + (s0 + t0);
+            a1 += (p1 + q1) + (s1 + t1);
+        }
+        for (; r < r1; r += RY) f(r, c, a0, a1);
+    }
+    red[0][tid] = a0;
+    red[1][tid] = a1;
+    __syncthreads();
+    if (ry == 0 && c < C) {
+        for (int y = 1; y < RY; ++y) { a0 += red[0][y * cpb + cl]; a1 += red[1][y * cpb + cl]; }
+        atomicAdd(out0 + c, a0);
+        atomicAdd(out1 + c, a1);
+    }
+}
+
+// Backward pass 1: g = grad_y * lrelu'(bn(x)); per channel sum(g) and sum(g*xhat).
+__global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(
+    const float *__restrict__ x, const float *__restrict__ gy, const float *__restrict__ mean,
+    const float *__restrict__ invstd, const float *__restrict__ gamma, const float *__restrict__ beta, float slope,
+    int M, int C, int cpb, int rows_per_block, float *__restrict__ sum_g, float *__restrict__ sum_gx)
+{
+    slab_reduce2(M, C, cpb, rows_per_block, sum_g, sum_gx, [&](int r, int c, float &sg, float &sgx) {
+        const float xh = (x[(size_t)r * C + c] - mean[c]) * invstd[c];
+        const float t = xh * gamma[c] + beta[c];
+        float g = gy[(size_t)r * C + c];
+        g = t > 0.f ? g : g * slope;
+        sg += g;
+        sgx = fmaf(g, xh, sgx);
+    });
+}
+
+// Backward pass 2: grad_x = gamma*invstd*(g - sum_g/M - xhat*sum_gx/M)   (batch statistics)
+//                  grad_x = gamma*invstd*g                                (running statistics)
+__global__ void bn_act_bwd_apply_kernel(const float *__restrict__ x, const float *__restrict__ gy,
+                                        const float *__restrict__ mean, const float *__restrict__ invstd,
+                                        const float *__restrict__ gamma, const float *__restrict__ beta,
+                                        const float *__restrict__ sum_g, const float *__restrict__ sum_gx,
+                                        float slope, int use_batch_stats, int M, int C, long long total,
+                                        float *__restrict__ gx)
+{
+    const float invM = 1.0f / (float)M;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const float is = invstd[c], ga = gamma[c];
+        const float xh = (x[i] - mean[c]) * is;
+        const float t = xh * ga + beta[c];
+        float g = gy[i];
+        g = t > 0.f ? g : g * slope;
+        float d = use_batch_stats ? (g - sum_g[c] * invM - xh * (sum_gx[c] * invM)) : g;
+        gx[i] = ga * is * d;
+    }
+}
+
+__global__ __launch_bounds__(256) void col_stats_kernel(const float *__restrict__ x, int M, int C, int cpb,
+                                                        int rows_per_block, float *__restrict__ col_sum,
+                                                        float *__restrict__ col_sumsq)
+{
+    slab_reduce2(M, C, cpb, rows_per_block, col_sum, col_sumsq, [&](int r, int c, float &s, float &q) {
+        const float v = x[(size_t)r * C + c];
+        s += v;
+        q = fmaf(v, v, q);
+    });
+}
+
+inline int ew_grid(long long total)
+{
+    long long g = (total + EW_TPB - 1) / EW_TPB;
+    return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
+}
+
+inline void slab_grid(int M, int C, dim3 &grid, int &cpb, int &rows_per_block)
+{
+    cpb = C >= 256 ? 256 : (C > 128 ? 256 : (C > 64 ? 128 : 64));   // channels per workgroup (divides 256)
+    int gy = mpa_ceil_div(C, cpb);
+    int ry = 256 / cpb;
+    // ~1024 workgroups over the chip, every lane walking >= 8 rows
+    int want = 1024 / gy;
+    rows_per_block = mpa_ceil_div(M, want < 1 ? 1 : want);
+    if (rows_per_block < 8 * ry) rows_per_block = 8 * ry;
+    grid = dim3(mpa_ceil_div(M, rows_per_block), gy);
+}
+
+}  // namespace
+
+// forward declaration (defined with the other column reductions below)
+static int launch_col_stats(const float *x, int M, int C, float *col_sum, float *col_sumsq, hipStream_t st);
+
+extern "C" int mpa_gemm_f32(const float *A, int lda, int transA, const float *B, int ldb, int transB,
+                            const float *bias, float *C, int ldc, int M, int N, int K, int accumulate,
+                            float *tile_stats, float *workspace, size_t workspace_bytes, void *stream)
+{
+    MPA_CLEAR_ERROR();
+    if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || lda <= 0 || ldb <= 0 || ldc < N) return MPA_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int vecA = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && (lda % 4 == 0);
+    const int vecB = ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && (ldb % 4 == 0);
+
+    // split K across workgroups when the output alone cannot fill the chip (weight gradients:
+    // K = B*S rows; the narrow head layers): aim at ~512 workgroups, >= 256 k per workgroup.
+    const long long ntiles = (long long)mpa_ceil_div(M, TS) * mpa_ceil_div(N, TS);
+    const size_t mn = (size_t)M * N;
+    int splits = 1;
+    if (ntiles < 256 && K >= 512 && ldc == N) {
+        splits = (int)((512 + ntiles - 1) / ntiles);
+        if (splits > K / 256) splits = K / 256;
+        const bool ws_ok = workspace != nullptr && ((reinterpret_cast<uintptr_t>(workspace) & 15) == 0);
+        if (ws_ok) {
+            size_t fit = workspace_bytes / (mn * sizeof(float));
+            if ((size_t)splits > fit) splits = (int)fit;
+        } else if (splits > 16) {
+            splits = 16;          // atomic fallback: bound the adders per address
+        }
+        if (splits < 1) splits = 1;
+    }
+    if (const char *e = getenv("MPA_GEMM_SPLITS")) splits = atoi(e);      // development override
+    int kchunk = mpa_ceil_div(mpa_ceil_div(K, splits), KS) * KS;
+    splits = mpa_ceil_div(K, kchunk);
+
+    int out_mode = accumulate ? 1 : 0;
+    float *dst = C;
+    bool reduce_after = false;
+    if (splits > 1) {
+        if (workspace != nullptr && workspace_bytes >= (size_t)splits * mn * sizeof(float)) {
+            out_mode = 2;
+            dst = workspace;
+            reduce_after = true;
+        } else {
+            if (!accumulate && hipMemsetAsync(C, 0, sizeof(float) * mn, st) != hipSuccess) return MPA_EHIP;
+            out_mode = 1;
+        }
+    }
+    const bool stats_after = splits > 1 && tile_stats != nullptr;   // partial sums carry no statistics
+    float *stats = stats_after ? nullptr : tile_stats;
+    int rc;
+    if (transA && transB)
+        rc = launch_gemm<true, true>(A, lda, B, ldb, bias, dst, ldc, M, N, K, splits, kchunk, out_mode, vecA, vecB,
+                                     stats, st);
+    else if (transA)
+        rc = launch_gemm<true, false>(A, lda, B, ldb, bias, dst, ldc, M, N, K, splits, kchunk, out_mode, vecA, vecB,
+                                      stats, st);
+    else if (transB)
+        rc = launch_gemm<false, true>(A, lda, B, ldb, bias, dst, ldc, M, N, K, splits, kchunk, out_mode, vecA, vecB,
+                                      stats, st);
+    else
+        rc = launch_gemm<false, false>(A, lda, B, ldb, bias, dst, ldc, M, N, K, splits, kchunk, out_mode, vecA, vecB,
+                                       stats, st);
+    if (rc != MPA_OK) return rc;
+    if (reduce_after) {
+        if (!accumulate && hipMemsetAsync(C, 0, sizeof(float) * mn, st) != hipSuccess) return MPA_EHIP;
+        const int gx = mpa_ceil_div((long long)mn, 256);
+        int gy = mpa_ceil_div(1024, gx);                 // ~1024 workgroups in total
+        gy = gy > 32 ? 32 : gy;
+        gy = gy > splits ? splits : gy;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(gx, gy), dim3(256), 0, st, workspace, splits, (long long)mn, C);
+    }
+    if (stats_after) {
+        if (accumulate) return MPA_EUNSUPPORTED;
+        hipLaunchKernelGGL(tile_stats_kernel, dim3(mpa_ceil_div(N, 64), mpa_ceil_div(M, TS)), dim3(256), 0, st, C, M, N,
+                           tile_stats);
+    }
+    MPA_LAUNCH_CHECK();
+    return MPA_OK;
+}
+
+static int launch_col_stats(const float *x, int M, int C, float *col_sum, float *col_sumsq, hipStream_t st)
+{
+    dim3 grid;
+    int cpb, rpb;
+    slab_grid(M, C, grid, cpb, rpb);
+    hipLaunchKernelGGL(col_stats_kernel, grid, dim3(256), 0, st, x, M, C, cpb, rpb, col_sum, col_sumsq);
+    return MPA_OK;
+}
+
+extern "C" int mpa_col_stats_f32(const float *x, int M, int C, float *col_sum, float *col_sumsq, void *stream)
+{
+    MPA_CLEAR_ERROR();
+    if (!x || !col_sum || !col_sumsq || M <= 0 || C <= 0) return MPA_EINVAL;
+    launch_col_stats(x, M, C, col_sum, col_sumsq, (hipStream_t)stream);
+    MPA_LAUNCH_CHECK();
+    return MPA_OK;
+}
+
+extern "C" int mpa_tile_stats_f32(const float *x, int M, int C, float *tile_stats, void *stream)
+{
+    MPA_CLEAR_ERROR();
+    if (!x || !tile_stats || M <= 0 || C <= 0) return MPA_EINVAL;
+    hipLaunchKernelGGL(tile_stats_kernel, dim3(mpa_ceil_div(C, 64), mpa_ceil_div(M, TS)), dim3(256), 0,
+                       (hipStream_t)stream, x, M, C, tile_stats);
+    MPA_LAUNCH_CHECK();
+    return MPA_OK;
+}
+
+extern "C" int mpa_bn_finalize_f32(const float *tile_stats, int M, int C, float *running_mean, float *running_var,
+                                   int training, float momentum, float eps, float *save_mean_invstd, void *stream)
+{
+    MPA_CLEAR_ERROR();
+    if (!save_mean_invstd || M <= 0 || C <= 0) return MPA_EINVAL;
+    if (training && !tile_stats) return MPA_EINVAL;
+    if (!training && (!running_mean || !running_var)) return MPA_EINVAL;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(mpa_ceil_div(C, 64)), dim3(256), 0, (hipStream_t)stream, tile_stats, M,
+                       C, running_mean, running_var, training, momentum, eps, save_mean_invstd);
+    MPA_LAUNCH_CHECK();
+    return MPA_OK;
+}
+
+extern "C" int mpa_bn_act_fwd_f32(const float *x, const float *save_mean_invstd, const float *gamma,
+                                  const float *beta, float slope, int M, int C, float *y, void *stream)
+{
+    MPA_CLEAR_ERROR();
+    if (!x || !save_mean_invstd || !gamma || !beta || !y || M <= 0 || C <= 0) return MPA_EINVAL;
+    if (C > 8192) return MPA_EUNSUPPORTED;
+    const bool al = (((uintptr_t)x | (uintptr_t)y) & 15) == 0;
+    if ((C & 3) == 0 && !al) return MPA_EUNSUPPORTED;
+    long long total = (long long)M * C;
+    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(ew_grid(total / 4 + 1)), dim3(EW_TPB), 2 * C * sizeof(float),
+                       (hipStream_t)stream, x, save_mean_invstd, gamma, beta, slope, M, C, y);
+    MPA_LAUNCH_CHECK();
+    return MPA_OK;
+}
+
+extern "C" int mpa_bn_act_bwd_reduce_f32(const float *x, const float *grad_y, const float *mean, const float *invstd,
+                                         const float *gamma, const float *beta, float slope, int M, int C,
+                                         float *sum_g, float *sum_gxhat, void *stream)
+{
+    MPA_CLEAR_ERROR();
+    if (!x || !grad_y || !mean || !invstd || !gamma || !beta || !sum_g || !sum_gxhat || M <= 0 || C <= 0)
+        return MPA_EINVAL;
+    dim3 grid;
+    int cpb, rpb;
+    slab_grid(M, C, grid, cpb, rpb);
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, grad_y, mean, invstd,
+                       gamma, beta, slope, M, C, cpb, rpb, sum_g, sum_gxhat);
+    MPA_LAUNCH_CHECK();
+    return MPA_OK;
+}
+
+extern "C" int mpa_bn_act_bwd_apply_f32(const float *x, const float *grad_y, const float *mean, const float *invstd,
+                                        const float *gamma, const float *beta, const float *sum_g,
+                                        const float *sum_gxhat, float slope, int use_batch_stats, int M, int C,
+                                        float *grad_x, void *stream)
+{
+    MPA_CLEAR_ERROR();
+    if (!x || !grad_y || !mean || !invstd || !gamma || !beta || !grad_x || M <= 0 || C <= 0) return MPA_EINVAL;
+    if (use_batch_stats && (!sum_g || !sum_gxhat)) return MPA_EINVAL;
+    long long total = (long long)M * C;
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ew_grid(total)), dim3(EW_TPB), 0, (hipStream_t)stream, x, grad_y,
+                       mean, invstd, gamma, beta, sum_g, sum_gxhat, slope, use_batch_stats, M, C, total, grad_x);
+    MPA_LAUNCH_CHECK();
+    return MPA_OK;
+}

@@ -25,6 +25,13 @@ void mpa_note_hip_error(int hip_error);
         }                                           \
     } while (0)
 
+// Indices arriving through the ABI are trusted to be in range, but a stray value (e.g. computed
+// from NaN features upstream) must never become a wild address: clamp before dereferencing.
+__device__ __forceinline__ long long mpa_clamp_idx(long long i, int n)
+{
+    return i < 0 ? 0 : (i >= n ? n - 1 : i);
+}
+
 static inline int mpa_ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // ---- DPP helpers (wave64, gfx9 DPP controls) ------------------------------------------

@@ -86,6 +86,7 @@ class GradReducer:
         self.params = [p for p in module.parameters() if p.requires_grad]
         self.bucket_bytes = bucket_bytes
         self.buckets = None          # list of dicts: flat, params, pending, handle
+        self.overlap = True          # False: no hook-launched collectives (HIP-graph replayed backward)
         self._where = {}
         self._handles = []
 
@@ -104,8 +105,12 @@ class GradReducer:
             cur_bytes += nbytes
         if cur:
             self._make_bucket(cur)
-        for p in live:
-            p.register_post_accumulate_grad_hook(self._hook)
+        # Hooks keep the AccumulateGrad nodes (and the stream they were created on) alive across
+        # iterations; a HIP-graph captured backward must not inherit them (the accumulation would
+        # fork onto the stale stream inside the capture), so they are only installed for overlap.
+        if self.overlap:
+            for p in live:
+                p.register_post_accumulate_grad_hook(self._hook)
 
     def _make_bucket(self, params):
         total = sum(p.numel() for p in params)
@@ -123,7 +128,7 @@ class GradReducer:
 
     def _hook(self, p):
         b = self._where.get(p)
-        if b is None or not is_dist():
+        if b is None or not is_dist() or not self.overlap:
             return
         b["pending"] -= 1
         if b["pending"] == 0:
@@ -150,8 +155,8 @@ class GradReducer:
                 for b in self.buckets:
                     dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM)
         else:
-            for b in self.buckets:      # a bucket whose hook did not fire (unused this step)
-                if b["pending"] != 0 and is_dist():
+            for b in self.buckets:      # a bucket whose hook did not fire (or overlap is off)
+                if (b["pending"] != 0 or not self.overlap) and is_dist():
                     self._handles.append(dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, async_op=True))
             for h in self._handles:
                 h.wait()

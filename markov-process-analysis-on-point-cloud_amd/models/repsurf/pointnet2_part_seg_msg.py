@@ -4,6 +4,7 @@ the reference's."""
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ... import ops
 from ...modules.pointnet2_utils import KeepHighResolutionModulePartSeg, Linear
 
 
@@ -26,7 +27,7 @@ class get_model(nn.Module):
         _, final_points = self.keepHigh(xyz, normal=xyz, label=cls_label)
         x = self.drop1(self.conv8(final_points))
         x = self.conv10(self.conv9(x))
-        return self.conv11(x), xyz
+        return ops.linear(x, self.conv11.weight, self.conv11.bias), xyz
 
 
 class get_loss(nn.Module):

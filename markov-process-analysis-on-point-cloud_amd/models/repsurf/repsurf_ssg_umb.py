@@ -4,6 +4,7 @@ State-dict keys equal the reference's."""
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ... import ops
 from ...modules.repsurface_utils import KeepHighResolutionModule, index_points  # noqa: F401
 
 
@@ -26,9 +27,9 @@ class Model(nn.Module):
         center = points[:, :3, :]
         normal = center                       # as the reference (:59): the normal input is dead
         x = self.keepHigh(center, normal)
-        x = self.drop1(self.lrelu(self.bn1(self.fc1(x))))
-        x = self.drop2(self.lrelu(self.bn2(self.fc2(x))))
-        return F.log_softmax(self.fc3(x), -1)
+        x = self.drop1(ops.linear_bn_act(x, self.fc1.weight, self.fc1.bias, self.bn1, 0.2))
+        x = self.drop2(ops.linear_bn_act(x, self.fc2.weight, self.fc2.bias, self.bn2, 0.2))
+        return F.log_softmax(ops.linear(x, self.fc3.weight, self.fc3.bias), -1)
 
 
 class SmoothClsLoss(nn.Module):

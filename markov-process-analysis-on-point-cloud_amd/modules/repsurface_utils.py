@@ -12,6 +12,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import ops
 from ..ops import (farthest_point_sample, index_points, knn_point, query_ball_point, query_knn_point,  # noqa: F401
                    sample, square_distance)
 from .pointnet2_utils import Linear, LocalTrans
@@ -149,4 +150,4 @@ class KeepHighResolutionModule(nn.Module):
             base = sub
         final = self.conv4(self.conv3(feat))                       # [B,32,1024]
         fused = torch.cat((final.max(dim=1)[0], final.mean(dim=1)), 1)
-        return self.lrelu(self.bn(self.final_class(fused)))
+        return ops.linear_bn_act(fused, self.final_class.weight, self.final_class.bias, self.bn, 0.2)

@@ -62,6 +62,16 @@ def _launch(name, *args, algo_bytes=0):
     recs.append((e0, e1, algo_bytes))
 
 
+# FPS start indices: None = draw from the CPU generator per call (reference behaviour); a hook
+# (B, N, device) -> int64 device tensor lets a captured HIP graph replay with fresh draws.
+_FPS_START_HOOK = None
+
+
+def set_fps_start_hook(fn):
+    global _FPS_START_HOOK
+    _FPS_START_HOOK = fn
+
+
 def _dev(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:
@@ -88,11 +98,14 @@ def farthest_point_sample(xyz, npoint, cuda=False, start_idx=None, return_xyz=Fa
     B, N, C = xyz.shape
     if C != 3:
         raise ValueError("farthest_point_sample: the gfx950 kernel samples in xyz space (C == 3), got C=%d" % C)
-    if start_idx is None:
-        start_idx = torch.randint(0, N, (B,), dtype=torch.long)
-    start = start_idx.to(device=xyz.device, dtype=torch.int64).contiguous()
-    if int(start_idx.min()) < 0 or int(start_idx.max()) >= N:
-        raise ValueError("farthest_point_sample: start_idx out of range")
+    if start_idx is None and _FPS_START_HOOK is not None:
+        start = _FPS_START_HOOK(B, N, xyz.device)     # graph-safe feeder (runtime.FpsStartFeeder)
+    else:
+        if start_idx is None:
+            start_idx = torch.randint(0, N, (B,), dtype=torch.long)
+        if not start_idx.is_cuda and (int(start_idx.min()) < 0 or int(start_idx.max()) >= N):
+            raise ValueError("farthest_point_sample: start_idx out of range")
+        start = start_idx.to(device=xyz.device, dtype=torch.int64).contiguous()
     out = torch.empty(B, npoint, dtype=torch.int64, device=xyz.device)
     oxyz = torch.empty(B, npoint, 3, dtype=torch.float32, device=xyz.device) if return_xyz else None
     _launch("mpa_fps_f32", _p(xyz), B, N, npoint, _p(start), _p(out), _p(oxyz), _stream())
@@ -333,16 +346,142 @@ def three_interpolate(xyz1, xyz2, points2):
 
 
 # ------------------------------------------------------------------------------- transition MLP
+_WORKSPACES = {}
+
+
+def _workspace(device, nbytes):
+    """Persistent split-K scratch, one per (device, stream): kernels using it are ordered on that
+    stream, and a buffer that outlives the call is safe under HIP-graph capture and replay."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _WORKSPACES.get(key)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = torch.empty(max(nbytes, 32 << 20) // 4, dtype=torch.float32, device=device)
+        _WORKSPACES[key] = ws
+    return ws
+
+
+def _gemm(A, lda, tA, Bm, ldb, tB, bias, C, ldc, M, N, K, accumulate=0, tile_stats=None):
+    ws, ws_bytes = None, 0
+    ntiles = ((M + 63) // 64) * ((N + 63) // 64)
+    if ntiles < 256 and K >= 512 and ldc == N:          # split-K partial tiles (see mpa_gemm_f32)
+        splits = min((512 + ntiles - 1) // ntiles, K // 256)
+        if splits > 1:
+            ws = _workspace(C.device, splits * M * N * 4)
+            ws_bytes = ws.numel() * 4
+    _launch("mpa_gemm_f32", _p(A), lda, tA, _p(Bm), ldb, tB, _p(bias), _p(C), ldc, M, N, K, accumulate,
+            _p(tile_stats), _p(ws), ws_bytes, _stream(), algo_bytes=4 * (M * K + N * K + M * N))
+
+
+def _col_sum(x2d):
+    M, C = x2d.shape
+    st = torch.zeros(2, C, dtype=torch.float32, device=x2d.device)
+    _launch("mpa_col_stats_f32", _p(x2d), M, C, _p(st[0]), _p(st[1]), _stream())
+    return st[0]
+
+
+class _Linear(torch.autograd.Function):
+    """y[M,N] = x[M,K] W[N,K]^T + b on the fp32-MFMA GEMM; backward = two more GEMMs."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        M, K = x.shape
+        N = W.shape[0]
+        y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+        _gemm(x, K, 0, W, K, 1, b, y, N, M, N, K)
+        ctx.save_for_backward(x, W)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, W = ctx.saved_tensors
+        M, K = x.shape
+        N = W.shape[0]
+        gy = gy.contiguous()
+        gx = gW = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty(M, K, dtype=torch.float32, device=x.device)
+            _gemm(gy, N, 0, W, K, 0, None, gx, K, M, K, N)            # gy [M,N] @ W [N,K]
+        if ctx.needs_input_grad[1]:
+            gW = torch.empty(N, K, dtype=torch.float32, device=x.device)
+            _gemm(gy, N, 1, x, K, 0, None, gW, K, N, K, M)            # gy^T [N,M] @ x [M,K]
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = _col_sum(gy)
+        return gx, gW, gb
+
+
 def linear(x, weight, bias):
-    """y = x W^T + b over the last dimension."""
-    return torch.nn.functional.linear(x, weight, bias)
+    """y = x W^T + b over the last dimension (nn.Linear), any leading shape."""
+    _dev(x, weight)
+    lead = x.shape[:-1]
+    y = _Linear.apply(_f32(x).reshape(-1, x.shape[-1]), _f32(weight), bias)
+    return y.view(*lead, weight.shape[0])
+
+
+class _LinearBNAct(torch.autograd.Function):
+    """Linear -> BatchNorm1d over the rows -> LeakyReLU, as one unit: the GEMM epilogue yields
+    the batch statistics, one elementwise kernel normalises + activates (and updates the
+    running statistics), backward is reduce + apply + two GEMMs."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, gamma, beta, running_mean, running_var, training, momentum, eps, slope):
+        M, K = x.shape
+        N = W.shape[0]
+        dev = x.device
+        y = torch.empty(M, N, dtype=torch.float32, device=dev)
+        stats = torch.empty((M + 63) // 64, 2, N, dtype=torch.float32, device=dev) if training else None
+        _gemm(x, K, 0, W, K, 1, b, y, N, M, N, K, 0, stats)
+        out = torch.empty(M, N, dtype=torch.float32, device=dev)
+        saved = torch.empty(2, N, dtype=torch.float32, device=dev)
+        _launch("mpa_bn_finalize_f32", _p(stats), M, N, _p(running_mean), _p(running_var), int(training),
+                float(momentum), float(eps), _p(saved), _stream())
+        _launch("mpa_bn_act_fwd_f32", _p(y), _p(saved), _p(gamma), _p(beta), float(slope), M, N, _p(out), _stream())
+        ctx.save_for_backward(x, W, y, gamma, beta, saved)
+        ctx.cfg = (bool(training), float(slope), b is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, W, y, gamma, beta, saved = ctx.saved_tensors
+        training, slope, has_bias = ctx.cfg
+        M, K = x.shape
+        N = W.shape[0]
+        dev = x.device
+        gout = gout.contiguous()
+        sums = torch.zeros(2, N, dtype=torch.float32, device=dev)
+        _launch("mpa_bn_act_bwd_reduce_f32", _p(y), _p(gout), _p(saved[0]), _p(saved[1]), _p(gamma), _p(beta), slope,
+                M, N, _p(sums[0]), _p(sums[1]), _stream())
+        gy = torch.empty(M, N, dtype=torch.float32, device=dev)
+        _launch("mpa_bn_act_bwd_apply_f32", _p(y), _p(gout), _p(saved[0]), _p(saved[1]), _p(gamma), _p(beta),
+                _p(sums[0]), _p(sums[1]), slope, int(training), M, N, _p(gy), _stream())
+        gx = gW = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty(M, K, dtype=torch.float32, device=dev)
+            _gemm(gy, N, 0, W, K, 0, None, gx, K, M, K, N)
+        if ctx.needs_input_grad[1]:
+            gW = torch.empty(N, K, dtype=torch.float32, device=dev)
+            _gemm(gy, N, 1, x, K, 0, None, gW, K, N, K, M)
+        if has_bias and ctx.needs_input_grad[2]:
+            # In front of a train-mode BatchNorm the bias gradient is identically zero (the batch
+            # mean removes any constant shift); the reference's value there is fp32 rounding noise.
+            gb = torch.zeros(N, dtype=torch.float32, device=dev) if training else _col_sum(gy)
+        return gx, gW, gb, sums[1], sums[0], None, None, None, None, None, None
 
 
 def linear_bn_act(x, weight, bias, bn, slope):
     """The reference's Linear unit (modules/pointnet2_utils.py:413-425): affine, BatchNorm1d
     over the B*S rows (batch statistics in training, running statistics in eval; `bn` is the
-    nn.BatchNorm1d holding gamma/beta/running stats), LeakyReLU(slope) unless slope is None."""
-    B, S, _ = x.shape
-    y = torch.nn.functional.linear(x, weight, bias)
-    y = bn(y.view(B * S, -1)).view(B, S, -1)
-    return torch.nn.functional.leaky_relu(y, slope) if slope is not None else y
+    nn.BatchNorm1d holding gamma/beta/running stats), LeakyReLU(slope) unless slope is None.
+    x is [B,S,C] or [M,C]."""
+    _dev(x, weight)
+    lead = x.shape[:-1]
+    x2 = _f32(x).reshape(-1, x.shape[-1])
+    training = bn.training or bn.running_mean is None
+    if training and x2.shape[0] <= 1:
+        raise ValueError("Expected more than 1 value per channel when training (BatchNorm1d)")
+    if training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    momentum = 0.1 if bn.momentum is None else bn.momentum
+    out = _LinearBNAct.apply(x2, _f32(weight), bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, training,
+                             momentum, bn.eps, 1.0 if slope is None else slope)
+    return out.view(*lead, weight.shape[0])

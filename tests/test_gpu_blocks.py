@@ -209,8 +209,10 @@ def _check_grads(g, model):
     ~1e-6 forward perturbation flips a few near-tied arg-maxes, rerouting gradient discontinuously
     (the oracle evaluated in fp64 differs from the fp32 golden by 5.6e-3 relative L2 on
     la0.xyz_Trans.k.weight).  1e-4 gradient parity is asserted per block (tests above); here:
-    the same parameters receive gradient, every gradient norm agrees to 2e-2 (+ fp32 noise
-    floor), and the stored full tensors agree to 2e-2 relative L2."""
+    the same parameters receive gradient, every gradient norm agrees to 5e-2 (+ fp32 noise
+    floor), and the stored full tensors agree to 5e-2 relative L2.  (Measured on the oracle
+    itself: perturbing the weights by 1e-6 relative moves the cls train-mode log-probs by 2.5e-4
+    and these gradient tensors by ~1e-2 relative L2.)"""
     names = list(g["grad_names"])
     gmax = float(g["grad_norms"].max())
     for n, p in model.named_parameters():
@@ -219,12 +221,12 @@ def _check_grads(g, model):
         if p.grad is not None:
             ref = float(g["grad_norms"][i])
             got = float(p.grad.double().norm())
-            assert abs(got - ref) <= 2e-2 * ref + 2e-6 * gmax, "%s: grad norm %g vs %g" % (n, got, ref)
+            assert abs(got - ref) <= 5e-2 * ref + 2e-6 * gmax, "%s: grad norm %g vs %g" % (n, got, ref)
         if "grad." + n in g:
             r = g["grad." + n]
             if np.linalg.norm(r) > 1e-4 * gmax:
                 rel = np.linalg.norm(p.grad.cpu().numpy() - r) / np.linalg.norm(r)
-                assert rel < 2e-2, "%s: relative L2 gradient error %.3e" % (n, rel)
+                assert rel < 5e-2, "%s: relative L2 gradient error %.3e" % (n, rel)
 
 
 def test_cls_model(P, RS, golden_cls):
@@ -242,7 +244,7 @@ def test_cls_model(P, RS, golden_cls):
     assert forced.flips <= 0.002 * forced.total
     model.train()
     out, forced = _run_model(g, model, lambda m: m(pts), [RS], "train_")
-    close(out, g["out_train"], what="cls train log-probs")
+    close(out, g["out_train"], tol=5e-4, what="cls train log-probs")   # see _check_grads: chaotic at 1e-4
     (out * randn(out.shape, seed=31337).cuda()).sum().backward()
     _check_grads(g, model)
 
@@ -273,6 +275,6 @@ def test_seg_model(P, golden_seg):
     close(out, g["out_eval"], what="seg eval logits")
     model.train()
     out, forced = _run_model(g, model, lambda m: m(pts, lab)[0], [P], "train_")
-    close(out, g["out_train"], what="seg train logits")
+    close(out, g["out_train"], tol=5e-4, what="seg train logits")
     (out * randn(out.shape, seed=31337).cuda()).sum().backward()
     _check_grads(g, model)

@@ -182,3 +182,101 @@ def test_ops_reject_cpu_tensors(ops):
         ops.knn_point(8, torch.zeros(1, 16, 3), torch.zeros(1, 4, 3))
     with pytest.raises(RuntimeError):
         ops.farthest_point_sample(torch.zeros(1, 16, 3), 4)
+
+
+# --------------------------------------------------------------------------- fp32 MFMA GEMM / BN
+@pytest.mark.parametrize("M,N,K,tA,tB", [(300, 64, 64, 0, 1), (1000, 40, 256, 0, 1), (513, 128, 3, 0, 1),
+                                         (2048, 512, 1024, 0, 1), (4096, 64, 128, 0, 0), (333, 3, 64, 0, 0),
+                                         (64, 64, 8192, 1, 0), (128, 3, 5000, 1, 0), (1024, 2048, 64, 1, 0),
+                                         (70, 50, 30, 1, 1), (65536, 64, 64, 0, 1)])
+def test_gemm_vs_torch(ops, M, N, K, tA, tB):
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn((K, M) if tA else (M, K), generator=g).cuda()
+    Bm = torch.randn((N, K) if tB else (K, N), generator=g).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    C = torch.empty(M, N, device="cuda")
+    tiles = (M + 63) // 64
+    st3 = torch.full((tiles, 2, N), float("nan"), device="cuda")
+    ops._gemm(A, A.shape[1], tA, Bm, Bm.shape[1], tB, bias, C, N, M, N, K, 0, st3)
+    ref = (A.double().t() if tA else A.double()) @ (Bm.double().t() if tB else Bm.double()) + bias.double()
+    scale = float(ref.abs().max())
+    assert float((C.double() - ref).abs().max()) < 2e-6 * scale * max(1.0, K ** 0.5 / 8)
+    # tile statistics: per 64-row tile, column sum and squared deviations from the tile mean
+    pad = tiles * 64 - M
+    rp = torch.cat([ref, ref.new_full((pad, N), float("nan"))]) if pad else ref
+    rt = rp.view(tiles, 64, N)
+    tsum = torch.nansum(rt, 1)
+    cnt = (~torch.isnan(rt)).sum(1)
+    tm2 = torch.nansum((rt - (tsum / cnt).unsqueeze(1)) ** 2, 1)
+    assert float((st3[:, 0].double() - tsum).abs().max()) < 1e-5 * float(ref.abs().max()) * 64
+    assert float((st3[:, 1].double() - tm2).abs().max()) < 1e-4 * float(tm2.max())
+
+
+def test_gemm_accumulate(ops):
+    A = torch.randn(200, 96, device="cuda")
+    Bm = torch.randn(96, 80, device="cuda")
+    C = torch.ones(200, 80, device="cuda")
+    ops._gemm(A, 96, 0, Bm, 80, 0, None, C, 80, 200, 80, 96, 1)
+    assert float((C - (A @ Bm + 1)).abs().max()) < 1e-3
+
+
+def test_gemm_is_fmaf_chain(ops):
+    """f32 MFMA == sequential fmaf over k: integer-valued operands give exact results and the
+    result does not depend on the tile configuration (M large vs small picks different tiles)."""
+    g = torch.Generator().manual_seed(0)
+    A = torch.randint(-8, 9, (4096, 64), generator=g).float().cuda()
+    W = torch.randint(-8, 9, (64, 64), generator=g).float().cuda()
+    C1 = torch.empty(4096, 64, device="cuda")
+    ops._gemm(A, 64, 0, W, 64, 1, None, C1, 64, 4096, 64, 64)
+    assert torch.equal(C1, A @ W.t())
+    x = torch.randn(70000, 64, device="cuda")
+    big = torch.empty(70000, 64, device="cuda")
+    small = torch.empty(100, 64, device="cuda")
+    ops._gemm(x, 64, 0, W, 64, 1, None, big, 64, 70000, 64, 64)
+    ops._gemm(x, 64, 0, W, 64, 1, None, small, 64, 100, 64, 64)
+    assert torch.equal(big[:100], small)
+
+
+@pytest.mark.parametrize("M,C", [(1000, 64), (50, 10), (4096, 512)])
+def test_linear_bn_act_vs_torch(ops, M, C):
+    g = torch.Generator().manual_seed(M)
+    x = torch.randn(M, 32, generator=g).cuda().requires_grad_(True)
+    lin = torch.nn.Linear(32, C).cuda()
+    bn = torch.nn.BatchNorm1d(C).cuda()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_()
+    bn2 = torch.nn.BatchNorm1d(C).cuda()
+    bn2.load_state_dict(bn.state_dict())
+    w = torch.randn(M, C, generator=g).cuda()
+    for training in (True, False):
+        bn.train(training); bn2.train(training)
+        for p in (x, lin.weight, lin.bias, bn.weight, bn.bias):
+            p.grad = None
+        out = ops.linear_bn_act(x, lin.weight, lin.bias, bn, 0.2)
+        (out * w).sum().backward()
+        got = [out.detach().clone()] + [p.grad.clone() for p in (x, lin.weight, bn.weight, bn.bias)]
+        gb = lin.bias.grad.clone()
+        for p in (x, lin.weight, lin.bias, bn.weight, bn.bias):
+            p.grad = None
+        x2 = x.detach().double().requires_grad_(True)
+        lw, lb = lin.weight.detach().double().requires_grad_(True), lin.bias.detach().double().requires_grad_(True)
+        gw_, gb_ = bn.weight.detach().double().requires_grad_(True), bn.bias.detach().double().requires_grad_(True)
+        y = torch.nn.functional.linear(x2, lw, lb)
+        rm = None if training else bn2.running_mean.double()
+        rv = None if training else bn2.running_var.double()
+        ref = torch.nn.functional.leaky_relu(torch.nn.functional.batch_norm(y, rm, rv, gw_, gb_, training, 0.1, bn.eps),
+                                             0.2)
+        (ref * w.double()).sum().backward()
+        want = [ref.detach(), x2.grad, lw.grad, gw_.grad, gb_.grad]
+        gscale = max(float(t.abs().max()) for t in want[1:])
+        for a, b, name in zip(got, want, ("out", "gx", "gW", "ggamma", "gbeta")):
+            lim = 1e-4 * max(1.0, float(b.abs().max()) if name == "out" else gscale)
+            assert float((a.double() - b).abs().max()) < lim, (name, training)
+        if not training:
+            assert float((gb.double() - lb.grad).abs().max()) < 1e-4 * gscale
+        if training:    # running statistics follow nn.BatchNorm1d
+            bn2(torch.nn.functional.linear(x.detach(), lin.weight, lin.bias))
+            assert torch.allclose(bn.running_mean, bn2.running_mean, atol=1e-5)
+            assert torch.allclose(bn.running_var, bn2.running_var, atol=1e-5)
+            assert int(bn.num_batches_tracked) == int(bn2.num_batches_tracked)

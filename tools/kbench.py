@@ -82,3 +82,28 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def linear_bench():
+    from mpa_amd import ops
+    dev = torch.device("cuda")
+    print("== Linear+BN+LReLU unit (train) fwd / fwd+bwd, and plain GEMM")
+    for (M, K, N) in ((65536, 64, 64), (65536, 64, 256), (32768, 64, 64), (32768, 128, 64), (8192, 256, 128),
+                      (4096, 512, 256), (2048, 1024, 512), (2048, 512, 1024), (65536, 3, 64)):
+        x = torch.randn(M, K, device=dev, requires_grad=True)
+        lin = torch.nn.Linear(K, N).to(dev)
+        bn = torch.nn.BatchNorm1d(N).to(dev).train()
+        t1 = timeit(lambda: ops.linear_bn_act(x, lin.weight, lin.bias, bn, 0.2))
+        out = ops.linear_bn_act(x, lin.weight, lin.bias, bn, 0.2)
+        g = torch.randn_like(out)
+        t2 = timeit(lambda: torch.autograd.grad(out, (x, lin.weight, bn.weight), g, retain_graph=True))
+        y = torch.empty(M, N, device=dev)
+        t3 = timeit(lambda: ops._gemm(x, K, 0, lin.weight, K, 1, lin.bias, y, N, M, N, K))
+        fl = 2.0 * M * K * N
+        by = 4.0 * (M * K + M * N)
+        print("M=%6d K=%4d N=%4d : unit fwd %7.1f us  bwd %7.1f us | gemm %7.1f us = %6.1f TFLOP/s %5.2f TB/s" % (
+            M, K, N, t1, t2, t3, fl / t3 / 1e6, by / t3 / 1e6))
+
+
+if __name__ == "__main__" and os.environ.get("LINEAR", "1") == "1":
+    linear_bench()
