@@ -11,6 +11,7 @@
 //   dist  : fl(fl(fl(-2*dot) + |q|^2) + |b|^2)                                 (A3)
 // Ties keep the lower base index (strict < on an ascending scan), the order a stable sort gives.
 #include "mpa_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -78,6 +79,46 @@ __device__ __forceinline__ float sum_sq_model(Ptr x, int C)
         s = s + sq;
     }
     return s;
+}
+
+// A2 for an LDS row read as float4 (conflict-free 16-B row reads instead of CT strided scalar
+// reads); same accumulation order as sum_sq_model for CT a multiple of 8.
+template <int CT>
+__device__ __forceinline__ float sum_sq_row4(const float *row)
+{
+    static_assert(CT % 8 == 0, "vector form of the A2 model");
+    constexpr int NVEC = CT / 8;
+    constexpr int A = NVEC < 4 ? NVEC : 4;
+    float acc[4][8];
+#pragma unroll
+    for (int m = 0; m < CT / 4; ++m) {
+        const float4 v = *reinterpret_cast<const float4 *>(row + 4 * m);
+        const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int idx = 4 * m + j, vv = idx / 8, l = idx % 8;
+            const float sq = e[j] * e[j];
+            if (vv < A) acc[vv][l] = sq;
+            else acc[vv % A][l] = acc[vv % A][l] + sq;
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int l = 0; l < 8; ++l) {
+        float t = acc[0][l];
+        if (A > 1) t = t + acc[1][l];
+        if (A > 2) t = t + acc[2][l];
+        if (A > 3) t = t + acc[3][l];
+        s = l == 0 ? t : s + t;
+    }
+    return s;
+}
+
+template <int CT>
+__device__ __forceinline__ float tile_row_norm(const float *row)
+{
+    if constexpr (CT % 8 == 0) return sum_sq_row4<CT>(row);
+    else return sum_sq_model<CT>(row, CT);
 }
 
 // LDS tile geometry: TB base rows of C floats, row stride C rounded up to a float4 multiple
@@ -289,6 +330,314 @@ __global__ void sqdist_kernel(const float *__restrict__ src, const float *__rest
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// MFMA kNN: the distance matrix tile by tile on the matrix cores, exact selection by
+// "bound, then filter".
+//
+// v_mfma_f32_32x32x2_f32 is bit-equal to a k-ordered fmaf chain (acc = fma(a_k, b_k, acc), one
+// rounding per product), which is exactly the reference's bmm dot (A1), so a 32x32 tile of dot
+// products comes out of C/2 MFMAs bit-identical to the scalar kernel above.  Operand orientation
+// puts the QUERY on the lane: A = 32 base rows, B = 32 queries, so lane l holds, for query
+// (l & 31), the 16 dots against base rows (r&3) + 8*(r>>2) + 4*(l>>5) of the tile.
+//
+// A workgroup owns 32 queries; its WAVES waves take the base tiles round-robin, each staging its
+// tile in a private LDS slab (no workgroup barrier inside a pass).  Keeping a sorted K-list per
+// lane costs ~6*K VALU ops per hit and SIMD execution pays it whenever ANY of 64 lanes hits, which
+// made selection 3x more expensive than the MFMAs.  Instead the distances are produced twice
+// (the matrix cores are otherwise idle):
+//   pass A  folds every candidate into one of 32 disjoint groups per query and keeps the group
+//           minima (4 v_min + one LDS atomic-min per 4 candidates).  The K-th smallest group
+//           minimum tau is an upper bound of the true K-th distance (the K smallest minima are K
+//           distinct points) -- and a tight one: ~1.2*K candidates pass it on random data.
+//   pass B  recomputes the tiles and appends the few candidates with d <= tau to a per-query LDS
+//           list (one compare per candidate, no sorting), which is then ranked by (distance,
+//           index): the order a stable ascending sort gives, i.e. the scalar kernel's tie rule.
+// If a list overflows (massive ties, e.g. duplicated points) the workgroup falls back to per-lane
+// sorted lists, merged by the same ranking.
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+template <int KMAX>
+__device__ __forceinline__ void list_insert(float (&bd)[KMAX], int (&bi)[KMAX], float d, int n)
+{
+#pragma unroll
+    for (int k = KMAX - 1; k > 0; --k) {
+        bool up = d < bd[k - 1];
+        bool here = d < bd[k];
+        bd[k] = up ? bd[k - 1] : (here ? d : bd[k]);
+        bi[k] = up ? bi[k - 1] : (here ? n : bi[k]);
+    }
+    bool h0 = d < bd[0];
+    bd[0] = h0 ? d : bd[0];
+    bi[0] = h0 ? n : bi[0];
+}
+
+// monotone float -> int key (handles the slightly negative distances the A3 rounding can give)
+__device__ __forceinline__ int f2key(float d)
+{
+    int b = __float_as_int(d);
+    return b >= 0 ? b : b ^ 0x7fffffff;
+}
+__device__ __forceinline__ bool lex_less(float d1, int n1, float d2, int n2)
+{
+    return d1 < d2 || (d1 == d2 && n1 < n2);
+}
+
+constexpr int KNN_CAP = 32;      // candidates kept per query in pass B
+constexpr int KNN_G = 32;        // groups per query in pass A
+
+template <int CT, int WAVES, int KMAX>
+__global__ __launch_bounds__(WAVES * 64) void knn_mfma_kernel(const float *__restrict__ base,
+                                                              const float *__restrict__ query, int N, int S, int K,
+                                                              float *__restrict__ out_dist,
+                                                              int64_t *__restrict__ out_idx)
+{
+    constexpr int CP = (CT + 3) & ~3;            // channels padded to a float4 multiple (C=3 -> 4)
+    constexpr int PITCH = CP + 4;                // LDS row pitch: (PITCH/4) odd -> conflict-free b128 rows
+    constexpr int NV = 32 * CP / 4 / 64;         // float4 staged per lane per tile (CP >= 8)
+    constexpr int NT_ = WAVES * 64;
+    extern __shared__ float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    float *slab = lds + wave * (32 * PITCH + 32);          // [32][PITCH] tile + [32] norms
+    float *snorm = slab + 32 * PITCH;
+    int *gmin = reinterpret_cast<int *>(lds + WAVES * (32 * PITCH + 32));   // [KNN_G][32] keys
+    float *tau = reinterpret_cast<float *>(gmin + KNN_G * 32);              // [32]
+    int *cnt = reinterpret_cast<int *>(tau + 32);                           // [32] (+ overflow flag at [32])
+    float *cand_d = reinterpret_cast<float *>(cnt + 64);                    // [32][KNN_CAP]
+    int *cand_i = reinterpret_cast<int *>(cand_d + 32 * KNN_CAP);           // [32][KNN_CAP]
+
+    const int b = blockIdx.y;
+    const int q0 = blockIdx.x * 32;
+    const float *bp = base + (size_t)b * N * CT;
+    const int qrow_i = min(q0 + l31, S - 1);
+    const float *qp = query + ((size_t)b * S + qrow_i) * CT;
+
+    // query operand: lane (j, half) holds q[j][2kk + half]; |q|^2 by the A2 model
+    float qv[CP / 2];
+#pragma unroll
+    for (int kk = 0; kk < CP / 2; ++kk) qv[kk] = (2 * kk + half < CT) ? qp[2 * kk + half] : 0.f;
+    const float qn = sum_sq_model<CT>(qp, CT);
+
+    for (int i = tid; i < KNN_G * 32; i += NT_) gmin[i] = 0x7f800000;      // +inf key
+    if (tid < 33) cnt[tid] = 0;
+    __syncthreads();
+
+    const int ntiles = (N + 31) / 32;
+    float4 stg[CP >= 8 ? NV : 1];
+    float stg3[2];
+    constexpr bool PREFETCH = CT <= 64;          // wide rows: the staging registers are needed for qv
+    auto load_tile = [&](int t) {
+        if (CT == 3) {
+            const float *src = bp + (size_t)t * 32 * 3;
+            const int lim = (min(32, N - t * 32)) * 3;
+            stg3[0] = lane < lim ? src[lane] : 0.f;
+            stg3[1] = lane + 64 < lim ? src[lane + 64] : 0.f;
+        } else {
+            const float4 *src = reinterpret_cast<const float4 *>(bp + (size_t)t * 32 * CT);
+            const int lim = min(32, N - t * 32) * (CP / 4);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const int i = lane + 64 * v;
+                stg[v] = i < lim ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+    auto store_tile = [&]() {
+        if (CT == 3) {
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                const int i = lane + 64 * v;
+                if (i < 96) slab[(i / 3) * PITCH + (i % 3)] = stg3[v];
+            }
+            if (lane < 32) slab[lane * PITCH + 3] = 0.f;
+        } else {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const int i = lane + 64 * v;
+                const int r = i / (CP / 4), c4 = i - r * (CP / 4);
+                *reinterpret_cast<float4 *>(slab + r * PITCH + 4 * c4) = stg[v];
+            }
+        }
+    };
+    auto copy_tile = [&](int t) {                // global -> LDS without holding the whole tile
+        const float4 *src = reinterpret_cast<const float4 *>(bp + (size_t)t * 32 * CT);
+        const int lim = min(32, N - t * 32) * (CP / 4);
+#pragma unroll 4
+        for (int v = 0; v < NV; ++v) {
+            const int i = lane + 64 * v;
+            const int r = i / (CP / 4), c4 = i - r * (CP / 4);
+            *reinterpret_cast<float4 *>(slab + r * PITCH + 4 * c4) = i < lim ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    // one tile: stage, norms (A2 model; rows beyond N get +inf so they never qualify), MFMA chain
+    floatx16 acc;
+    auto tile_dots = [&](int t, bool first) {
+        if (PREFETCH) {
+            if (first) load_tile(t);
+            store_tile();
+            if (t + WAVES < ntiles) load_tile(t + WAVES);      // in flight during this tile's MFMAs
+        } else {
+            copy_tile(t);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 32) snorm[lane] = (t * 32 + lane < N) ? tile_row_norm<CT>(slab + lane * PITCH) : INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const float *row = slab + l31 * PITCH;
+#pragma unroll
+        for (int m = 0; m < CP / 4; ++m) {
+            const float4 a = *reinterpret_cast<const float4 *>(row + 4 * m);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? a.y : a.x, qv[2 * m], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? a.w : a.z, qv[2 * m + 1], acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+#define KNN_DIST(r) ((-2.0f * acc[r] + qn) + snorm[((r) & 3) + 8 * ((r) >> 2) + 4 * half])
+
+    bool fast = (ntiles * 8 >= K) && K <= KNN_CAP;
+    if (fast) {
+        // ---------------- pass A: group minima
+        for (int t = wave, it = 0; t < ntiles; t += WAVES, ++it) {
+            tile_dots(t, it == 0);
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                float m = fminf(fminf(KNN_DIST(4 * qd), KNN_DIST(4 * qd + 1)),
+                                fminf(KNN_DIST(4 * qd + 2), KNN_DIST(4 * qd + 3)));
+                const int g = (t * 8 + qd * 2 + half) & (KNN_G - 1);
+                atomicMin(gmin + g * 32 + l31, f2key(m));
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        __syncthreads();
+        // tau[q] = K-th smallest group minimum (rank by (key, group))
+        for (int item = tid; item < 32 * KNN_G; item += NT_) {
+            const int q = item & 31, g = item >> 5;
+            const int v = gmin[g * 32 + q];
+            int rank = 0;
+            for (int o = 0; o < KNN_G; ++o) {
+                const int u = gmin[o * 32 + q];
+                rank += (u < v || (u == v && o < g)) ? 1 : 0;
+            }
+            if (rank == K - 1) tau[q] = __int_as_float(v >= 0 ? v : v ^ 0x7fffffff);
+        }
+        __syncthreads();
+        // ---------------- pass B: collect d <= tau
+        const float tq = tau[l31];
+        for (int t = wave, it = 0; t < ntiles; t += WAVES, ++it) {
+            tile_dots(t, it == 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float d = KNN_DIST(r);
+                const int n = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (d <= tq && n < N) {
+                    const int slot = atomicAdd(cnt + l31, 1);
+                    if (slot < KNN_CAP) {
+                        cand_d[l31 * KNN_CAP + slot] = d;
+                        cand_i[l31 * KNN_CAP + slot] = n;
+                    } else {
+                        cnt[32] = 1;                 // overflow: redo this workgroup the slow way
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        __syncthreads();
+        fast = cnt[32] == 0;
+        if (fast) {
+            for (int item = tid; item < 32 * KNN_CAP; item += NT_) {
+                const int q = item / KNN_CAP, sl = item - q * KNN_CAP;
+                const int n_q = cnt[q];
+                if (sl < n_q && q0 + q < S) {
+                    const float d = cand_d[q * KNN_CAP + sl];
+                    const int n = cand_i[q * KNN_CAP + sl];
+                    int rank = 0;
+                    for (int o = 0; o < n_q; ++o)
+                        rank += lex_less(cand_d[q * KNN_CAP + o], cand_i[q * KNN_CAP + o], d, n) ? 1 : 0;
+                    if (rank < K) {
+                        const size_t o_ = ((size_t)b * S + q0 + q) * K + rank;
+                        out_idx[o_] = n;
+                        if (out_dist) out_dist[o_] = d;
+                    }
+                }
+            }
+            return;
+        }
+        __syncthreads();
+    }
+
+    // ---------------- slow path: per-lane sorted lists (two half-lists per query and wave)
+    float bd[KMAX];
+    int bi[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) { bd[k] = INFINITY; bi[k] = 0; }
+    for (int t = wave, it = 0; t < ntiles; t += WAVES, ++it) {
+        tile_dots(t, it == 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float d = KNN_DIST(r);
+            if (d < bd[KMAX - 1]) list_insert<KMAX>(bd, bi, d, t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+#undef KNN_DIST
+    // merge the 2*WAVES sorted partial lists of every query: every lane ranks its own elements in
+    // the union (own position + lexicographically smaller pairs in each other list)
+    __syncthreads();
+    constexpr int NL = 2 * WAVES;
+    float *cd = lds;                                              // [32][NL][KMAX]
+    int *ci = reinterpret_cast<int *>(lds + 32 * NL * KMAX);
+    const int list = wave * 2 + half;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        cd[(l31 * NL + list) * KMAX + k] = bd[k];
+        ci[(l31 * NL + list) * KMAX + k] = bi[k];
+    }
+    __syncthreads();
+    if (q0 + l31 < S) {
+        const size_t o = ((size_t)b * S + q0 + l31) * K;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const float d = bd[k];
+            const int n = bi[k];
+            int rank = k;
+            for (int ol = 0; ol < NL; ++ol) {
+                if (ol == list) continue;
+                for (int e = 0; e < KMAX; ++e)
+                    rank += lex_less(cd[(l31 * NL + ol) * KMAX + e], ci[(l31 * NL + ol) * KMAX + e], d, n) ? 1 : 0;
+            }
+            if (rank < K && d < INFINITY) {
+                out_idx[o + rank] = n;
+                if (out_dist) out_dist[o + rank] = d;
+            }
+        }
+    }
+}
+
+template <int CT, int WAVES, int KMAX>
+int launch_knn_mfma(const float *base, const float *query, int B, int N, int S, int K, float *od, int64_t *oi,
+                    hipStream_t st)
+{
+    constexpr int CP = (CT + 3) & ~3;
+    constexpr size_t work = ((size_t)WAVES * (32 * (CP + 4) + 32) + KNN_G * 32 + 32 + 64 + 2 * 32 * KNN_CAP) *
+                            sizeof(float);
+    constexpr size_t merge = (size_t)32 * 2 * WAVES * KMAX * 8;
+    constexpr size_t lds = work > merge ? work : merge;
+    static_assert(lds <= 64 * 1024, "stay under the default dynamic LDS limit");
+    dim3 grid(mpa_ceil_div(S, 32), B);
+    hipLaunchKernelGGL((knn_mfma_kernel<CT, WAVES, KMAX>), grid, dim3(WAVES * 64), lds, st, base, query, N, S, K, od,
+                       oi);
+    MPA_LAUNCH_CHECK();
+    return MPA_OK;
+}
+
+template <int CT, int WAVES>
+int launch_knn_mfma_k(const float *base, const float *query, int B, int N, int S, int K, float *od, int64_t *oi,
+                      hipStream_t st)
+{
+    if (K <= 8) return launch_knn_mfma<CT, WAVES, 8>(base, query, B, N, S, K, od, oi, st);
+    return launch_knn_mfma<CT, WAVES, 32>(base, query, B, N, S, K, od, oi, st);
+}
+
 int pick_tb(int C, int N, bool query_in_lds)
 {
     int LD = tile_ld(C);
@@ -360,11 +709,21 @@ extern "C" int mpa_knn_f32(const float *base, const float *query, int B, int N, 
     if (K > 32 || K > N) return MPA_EUNSUPPORTED;
     if (C >= 8 && (C & 7)) return MPA_EUNSUPPORTED;   // norm rounding model only validated for C<8 or C%8==0
     hipStream_t st = (hipStream_t)stream;
-    switch (C) {
+    const bool al16 = (((uintptr_t)base | (uintptr_t)query) & 15) == 0;
+    const bool scalar_path = getenv("MPA_KNN_SCALAR") != nullptr;       // development: the VALU kernel
+    if (!scalar_path && (C == 3 || al16)) {
+        switch (C) {                                                    // matrix-core kernel
+        case 3: return launch_knn_mfma_k<3, 4>(base, query, B, N, S, K, out_dist, out_idx, st);
+        case 32: return launch_knn_mfma_k<32, 4>(base, query, B, N, S, K, out_dist, out_idx, st);
+        case 64: return launch_knn_mfma_k<64, 4>(base, query, B, N, S, K, out_dist, out_idx, st);
+        case 128: return launch_knn_mfma_k<128, 2>(base, query, B, N, S, K, out_dist, out_idx, st);
+        case 256: return launch_knn_mfma_k<256, 1>(base, query, B, N, S, K, out_dist, out_idx, st);
+        default: break;
+        }
+    }
+    switch (C) {                                                        // generic VALU kernel
     case 3: return launch_knn_k<3>(base, query, B, N, S, C, K, out_dist, out_idx, st);
     case 64: return launch_knn_k<64>(base, query, B, N, S, C, K, out_dist, out_idx, st);
-    case 128: return launch_knn_k<128>(base, query, B, N, S, C, K, out_dist, out_idx, st);
-    case 256: return launch_knn_k<256>(base, query, B, N, S, C, K, out_dist, out_idx, st);
     default: return launch_knn_k<0>(base, query, B, N, S, C, K, out_dist, out_idx, st);
     }
 }
