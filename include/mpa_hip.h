@@ -133,13 +133,18 @@ int mpa_col_stats_f32(const float *x, int M, int C, float *col_sum, float *col_s
 /* BatchNorm1d statistics: save_mean_invstd [2][C] <- (mean, 1/sqrt(var+eps)).  training != 0:
  * from tile_stats over the M rows (biased variance), and running_mean/var (may be NULL) are
  * updated with `momentum` (unbiased variance) as nn.BatchNorm1d does; training == 0: from the
- * running statistics (tile_stats ignored). */
+ * running statistics (tile_stats ignored).  zero_buf (optional): zero_count floats cleared by the
+ * same launch -- the [2][C] accumulator that mpa_bn_act_bwd_reduce_f32 later adds into. */
 int mpa_bn_finalize_f32(const float *tile_stats, int M, int C, float *running_mean, float *running_var,
-                        int training, float momentum, float eps, float *save_mean_invstd, void *stream);
-/* y = leaky_relu((x - mean[c]) * invstd[c] * gamma[c] + beta[c], slope) over [M,C]  (slope = 1:
- * no activation).  In place allowed (y == x). */
+                        int training, float momentum, float eps, float *save_mean_invstd, float *zero_buf,
+                        int zero_count, void *stream);
+/* y = residual + leaky_relu((x - mean[c]) * invstd[c] * gamma[c] + beta[c], slope) over [M,C]
+ * (slope = 1: no activation; residual may be NULL -- it is LocalTrans' `residual + ffn(context)`,
+ * modules/pointnet2_utils.py:572, fused into the same pass).  In place allowed (y == x). */
 int mpa_bn_act_fwd_f32(const float *x, const float *save_mean_invstd, const float *gamma, const float *beta,
-                       float slope, int M, int C, float *y, void *stream);
+                       const float *residual, float slope, int M, int C, float *y, void *stream);
+/* out[c] += sum over the M rows of x[r*ld + c]  (bias gradients; out [C] cleared by the caller). */
+int mpa_col_sum_f32(const float *x, int M, int C, int ld, float *out, void *stream);
 /* backward of y = lrelu(bn(x)): pass 1 accumulates (caller zeroes) sum_g[c] = sum g and
  * sum_gxhat[c] = sum g*xhat with g = grad_y * lrelu'(.)  (these are dbeta and dgamma);
  * pass 2 writes grad_x = gamma*invstd*(g - sum_g/M - xhat*sum_gxhat/M) (use_batch_stats != 0)

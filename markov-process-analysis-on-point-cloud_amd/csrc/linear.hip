@@ -37,7 +37,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const float *__restrict__ A
                                                      const float *__restrict__ B, int ldb,
                                                      const float *__restrict__ bias, float *__restrict__ C, int ldc,
                                                      int M, int N, int K, int kchunk, int out_mode, int vecA,
-                                                     int vecB, float *__restrict__ tile_stats)
+                                                     int vecB, float *__restrict__ tile_stats, float *__restrict__ zero_c)
 {
     // out_mode 0: C = result (+bias);  1: atomicAdd into C;  2: split-K partial slab
     //             C + blockIdx.z*M*ldc (plain stores, summed by splitk_reduce_kernel).
@@ -199,7 +199,21 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const float *__restrict__ A
         }
         return;
     }
-    if (out_mode == 2) C += (size_t)blockIdx.z * M * ldc;
+    if (out_mode == 2) {
+        // split-K slabs are summed into the real output by splitk_reduce_kernel (atomics): the z = 0
+        // workgroups clear their tile of it here, saving a separate memset launch
+        if (zero_c != nullptr && blockIdx.z == 0) {
+            const int cz = n0 + (tid & 15) * 4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int rz = m0 + (tid >> 4) + 16 * q;
+                if (rz < M)
+                    for (int e = 0; e < 4; ++e)
+                        if (cz + e < N) zero_c[(size_t)rz * ldc + cz + e] = 0.f;
+            }
+        }
+        C += (size_t)blockIdx.z * M * ldc;
+    }
 
     const int c4 = (tid & 15) * 4;            // this lane's 4 columns (same for its 4 rows)
     const int col = n0 + c4;
@@ -297,13 +311,14 @@ constexpr size_t gemm_lds_bytes(bool, bool) { return sizeof(float) * 2 * KS * (T
 
 template <bool TA, bool TB>
 int launch_gemm(const float *A, int lda, const float *B, int ldb, const float *bias, float *C, int ldc, int M, int N,
-                int K, int splits, int kchunk, int out_mode, int vecA, int vecB, float *stats, hipStream_t st)
+                int K, int splits, int kchunk, int out_mode, int vecA, int vecB, float *stats, float *zero_c,
+                hipStream_t st)
 {
     constexpr size_t lds = gemm_lds_bytes(TA, TB);
     static_assert(lds >= sizeof(float) * 4 * TS * TS && lds <= 64 * 1024, "reduction region fits, no opt-in");
     dim3 grid(mpa_ceil_div(M, TS) * mpa_ceil_div(N, TS), 1, splits);
     hipLaunchKernelGGL((gemm_kernel<TA, TB>), grid, dim3(NT), lds, st, A, lda, B, ldb, bias, C, ldc, M, N, K, kchunk,
-                       out_mode, vecA, vecB, stats);
+                       out_mode, vecA, vecB, stats, zero_c);
     return MPA_OK;
 }
 
@@ -377,15 +392,21 @@ __global__ __launch_bounds__(256) void tile_stats_kernel(const float *__restrict
 // mean = sum(sum_t)/M, M2 = sum(M2_t + n_t*(sum_t/n_t - mean)^2), biased variance M2/M -- in a
 // fixed order (deterministic), and update the running statistics (momentum, unbiased variance)
 // as nn.BatchNorm1d does.  Eval: from the running statistics.  out = save [2][C] (mean, invstd).
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float *__restrict__ tile_stats, int M, int C,
-                                                          float *__restrict__ running_mean,
-                                                          float *__restrict__ running_var, int training,
-                                                          float momentum, float eps, float *__restrict__ save)
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float *__restrict__ tile_stats, int M, int C,
+                                                           float *__restrict__ running_mean,
+                                                           float *__restrict__ running_var, int training,
+                                                           float momentum, float eps, float *__restrict__ save,
+                                                           float *__restrict__ zero_me, int zero_n)
 {
-    __shared__ float red[4][64];
+    // 1024 lanes = 16 tile-groups x 64 channels: up to 1024 tiles per channel are summed as 16
+    // interleaved partial chains (4 independent loads in flight each), then combined in LDS in a
+    // fixed order -> deterministic.
+    __shared__ float red[16][64];
     __shared__ float mean_s[64];
     const int tid = threadIdx.x, cl = tid & 63, g = tid >> 6;
     const int c = blockIdx.x * 64 + cl;
+    if (blockIdx.x == 0)
+        for (int i = tid; i < zero_n; i += 1024) zero_me[i] = 0.f;     // scratch the backward pass accumulates into
     if (!training) {
         if (g == 0 && c < C) {
             save[c] = running_mean[c];
@@ -394,26 +415,49 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float *__restric
         return;
     }
     const int tiles = (M + TS - 1) / TS;
-    float s = 0.f;
-    if (c < C)
-        for (int t = g; t < tiles; t += 4) s += tile_stats[(size_t)t * 2 * C + c];
-    red[g][cl] = s;
+    const size_t st = (size_t)2 * C;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < C) {
+        int t = g;
+        for (; t + 48 < tiles; t += 64) {
+            s0 += tile_stats[(size_t)t * st + c];
+            s1 += tile_stats[(size_t)(t + 16) * st + c];
+            s2 += tile_stats[(size_t)(t + 32) * st + c];
+            s3 += tile_stats[(size_t)(t + 48) * st + c];
+        }
+        for (; t < tiles; t += 16) s0 += tile_stats[(size_t)t * st + c];
+    }
+    red[g][cl] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (g == 0) mean_s[cl] = ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) / (float)M;
+    if (g == 0) {
+        float s = 0.f;
+#pragma unroll
+        for (int y = 0; y < 16; ++y) s += red[y][cl];
+        mean_s[cl] = s / (float)M;
+    }
     __syncthreads();
     const float mean = mean_s[cl];
-    float m2 = 0.f;
-    if (c < C)
-        for (int t = g; t < tiles; t += 4) {
+    float m0 = 0.f, m1 = 0.f, m2_ = 0.f, m3 = 0.f;
+    if (c < C) {
+        auto term = [&](int t) {
             const float nt = (float)min(TS, M - t * TS);
-            const float d = tile_stats[(size_t)t * 2 * C + c] / nt - mean;
-            m2 += tile_stats[(size_t)t * 2 * C + C + c] + nt * d * d;
+            const float d = tile_stats[(size_t)t * st + c] / nt - mean;
+            return tile_stats[(size_t)t * st + C + c] + nt * d * d;
+        };
+        int t = g;
+        for (; t + 48 < tiles; t += 64) {
+            m0 += term(t); m1 += term(t + 16); m2_ += term(t + 32); m3 += term(t + 48);
         }
+        for (; t < tiles; t += 16) m0 += term(t);
+    }
     __syncthreads();
-    red[g][cl] = m2;
+    red[g][cl] = (m0 + m1) + (m2_ + m3);
     __syncthreads();
     if (g == 0 && c < C) {
-        const float var = ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) / (float)M;
+        float m2 = 0.f;
+#pragma unroll
+        for (int y = 0; y < 16; ++y) m2 += red[y][cl];
+        const float var = m2 / (float)M;
         save[c] = mean;
         save[C + c] = 1.0f / sqrtf(var + eps);
         if (running_mean) {
@@ -428,8 +472,9 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float *__restric
 // per-channel scale/shift in LDS, then streams its share of the rows with float4 accesses.
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float *__restrict__ x, const float *__restrict__ save,
                                                          const float *__restrict__ gamma,
-                                                         const float *__restrict__ beta, float slope, int M, int C,
-                                                         float *__restrict__ y)
+                                                         const float *__restrict__ beta,
+                                                         const float *__restrict__ residual, float slope, int M,
+                                                         int C, float *__restrict__ y)
 {
     extern __shared__ float ss[];          // scale[C], shift[C]
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -452,6 +497,10 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float *__restrict
             o.z = fmaf(v.z, sc.z, sh.z); o.w = fmaf(v.w, sc.w, sh.w);
             o.x = o.x > 0.f ? o.x : o.x * slope; o.y = o.y > 0.f ? o.y : o.y * slope;
             o.z = o.z > 0.f ? o.z : o.z * slope; o.w = o.w > 0.f ? o.w : o.w * slope;
+            if (residual != nullptr) {
+                const float4 r = reinterpret_cast<const float4 *>(residual)[i];
+                o.x = r.x + o.x; o.y = r.y + o.y; o.z = r.z + o.z; o.w = r.w + o.w;
+            }
             reinterpret_cast<float4 *>(y)[i] = o;
         }
     } else {
@@ -459,9 +508,40 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float *__restrict
         for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
              i += (long long)gridDim.x * blockDim.x) {
             const int c = (int)(i % C);
-            const float t = fmaf(x[i], ss[c], ss[C + c]);
-            y[i] = t > 0.f ? t : t * slope;
+            float t = fmaf(x[i], ss[c], ss[C + c]);
+            t = t > 0.f ? t : t * slope;
+            y[i] = residual != nullptr ? residual[i] + t : t;
         }
+    }
+}
+
+// out[c] += sum over the M rows of x[r*ld + c]   (bias gradients; `out` cleared by the caller)
+__global__ __launch_bounds__(256) void col_sum_kernel(const float *__restrict__ x, int M, int C, int ld, int cpb,
+                                                      int rows_per_block, float *__restrict__ out)
+{
+    __shared__ float red[256];
+    const int tid = threadIdx.x;
+    const int ry = tid / cpb, cl = tid - ry * cpb, RY = blockDim.x / cpb;
+    const int c = blockIdx.y * cpb + cl;
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(M, r0 + rows_per_block);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (c < C) {
+        int r = r0 + ry;
+        for (; r + 3 * RY < r1; r += 4 * RY) {
+            a0 += x[(size_t)r * ld + c];
+            a1 += x[(size_t)(r + RY) * ld + c];
+            a2 += x[(size_t)(r + 2 * RY) * ld + c];
+            a3 += x[(size_t)(r + 3 * RY) * ld + c];
+        }
+        for (; r < r1; r += RY) a0 += x[(size_t)r * ld + c];
+    }
+    red[tid] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (ry == 0 && c < C) {
+        float s = red[cl];
+        for (int y = 1; y < RY; ++y) s += red[y * cpb + cl];
+        atomicAdd(out + c, s);
     }
 }
 
@@ -616,24 +696,24 @@ extern "C" int mpa_gemm_f32(const float *A, int lda, int transA, const float *B,
             out_mode = 1;
         }
     }
+    float *zero_c = (reduce_after && !accumulate) ? C : nullptr;
     const bool stats_after = splits > 1 && tile_stats != nullptr;   // partial sums carry no statistics
     float *stats = stats_after ? nullptr : tile_stats;
     int rc;
     if (transA && transB)
         rc = launch_gemm<true, true>(A, lda, B, ldb, bias, dst, ldc, M, N, K, splits, kchunk, out_mode, vecA, vecB,
-                                     stats, st);
+                                     stats, zero_c, st);
     else if (transA)
         rc = launch_gemm<true, false>(A, lda, B, ldb, bias, dst, ldc, M, N, K, splits, kchunk, out_mode, vecA, vecB,
-                                      stats, st);
+                                      stats, zero_c, st);
     else if (transB)
         rc = launch_gemm<false, true>(A, lda, B, ldb, bias, dst, ldc, M, N, K, splits, kchunk, out_mode, vecA, vecB,
-                                      stats, st);
+                                      stats, zero_c, st);
     else
         rc = launch_gemm<false, false>(A, lda, B, ldb, bias, dst, ldc, M, N, K, splits, kchunk, out_mode, vecA, vecB,
-                                       stats, st);
+                                       stats, zero_c, st);
     if (rc != MPA_OK) return rc;
     if (reduce_after) {
-        if (!accumulate && hipMemsetAsync(C, 0, sizeof(float) * mn, st) != hipSuccess) return MPA_EHIP;
         const int gx = mpa_ceil_div((long long)mn, 256);
         int gy = mpa_ceil_div(1024, gx);                 // ~1024 workgroups in total
         gy = gy > 32 ? 32 : gy;
@@ -678,29 +758,44 @@ extern "C" int mpa_tile_stats_f32(const float *x, int M, int C, float *tile_stat
 }
 
 extern "C" int mpa_bn_finalize_f32(const float *tile_stats, int M, int C, float *running_mean, float *running_var,
-                                   int training, float momentum, float eps, float *save_mean_invstd, void *stream)
+                                   int training, float momentum, float eps, float *save_mean_invstd, float *zero_buf,
+                                   int zero_count, void *stream)
 {
     MPA_CLEAR_ERROR();
     if (!save_mean_invstd || M <= 0 || C <= 0) return MPA_EINVAL;
     if (training && !tile_stats) return MPA_EINVAL;
     if (!training && (!running_mean || !running_var)) return MPA_EINVAL;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(mpa_ceil_div(C, 64)), dim3(256), 0, (hipStream_t)stream, tile_stats, M,
-                       C, running_mean, running_var, training, momentum, eps, save_mean_invstd);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(mpa_ceil_div(C, 64)), dim3(1024), 0, (hipStream_t)stream, tile_stats, M,
+                       C, running_mean, running_var, training, momentum, eps, save_mean_invstd, zero_buf,
+                       zero_buf ? zero_count : 0);
+    MPA_LAUNCH_CHECK();
+    return MPA_OK;
+}
+
+extern "C" int mpa_col_sum_f32(const float *x, int M, int C, int ld, float *out, void *stream)
+{
+    MPA_CLEAR_ERROR();
+    if (!x || !out || M <= 0 || C <= 0 || ld < C) return MPA_EINVAL;
+    dim3 grid;
+    int cpb, rpb;
+    slab_grid(M, C, grid, cpb, rpb);
+    hipLaunchKernelGGL(col_sum_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, M, C, ld, cpb, rpb, out);
     MPA_LAUNCH_CHECK();
     return MPA_OK;
 }
 
 extern "C" int mpa_bn_act_fwd_f32(const float *x, const float *save_mean_invstd, const float *gamma,
-                                  const float *beta, float slope, int M, int C, float *y, void *stream)
+                                  const float *beta, const float *residual, float slope, int M, int C, float *y,
+                                  void *stream)
 {
     MPA_CLEAR_ERROR();
     if (!x || !save_mean_invstd || !gamma || !beta || !y || M <= 0 || C <= 0) return MPA_EINVAL;
     if (C > 8192) return MPA_EUNSUPPORTED;
-    const bool al = (((uintptr_t)x | (uintptr_t)y) & 15) == 0;
+    const bool al = (((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual) & 15) == 0;
     if ((C & 3) == 0 && !al) return MPA_EUNSUPPORTED;
     long long total = (long long)M * C;
     hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(ew_grid(total / 4 + 1)), dim3(EW_TPB), 2 * C * sizeof(float),
-                       (hipStream_t)stream, x, save_mean_invstd, gamma, beta, slope, M, C, y);
+                       (hipStream_t)stream, x, save_mean_invstd, gamma, beta, residual, slope, M, C, y);
     MPA_LAUNCH_CHECK();
     return MPA_OK;
 }

@@ -82,7 +82,12 @@ class GradReducer:
     The first backward discovers which parameters receive gradients; from then on their .grad
     tensors are views into flat buckets and reductions start from autograd hooks."""
 
-    def __init__(self, module, bucket_bytes=16 << 20):
+    def __init__(self, module, bucket_bytes=16 << 20, direct=False):
+        # direct=True: the libmpa backward kernels write parameter gradients straight into the flat
+        # buckets (ops._direct) instead of handing tensors to autograd's AccumulateGrad -- valid when
+        # every parameter is used once per step (true for the cls / part-seg models) and
+        # zero_grad() is called every step.
+        self.direct = direct
         self.params = [p for p in module.parameters() if p.requires_grad]
         self.bucket_bytes = bucket_bytes
         self.buckets = None          # list of dicts: flat, params, pending, handle
@@ -122,6 +127,8 @@ class GradReducer:
             v.copy_(p.grad)
             p.grad = v
             b["views"].append(v)
+            if self.direct:
+                p._mpa_grad_buf = v
             self._where[p] = b
             off += p.numel()
         self.buckets.append(b)

@@ -50,11 +50,16 @@ class Linear(nn.Module):
     def forward(self, input):
         if input.dim() != 3:
             raise ValueError("Linear expects a [B,S,C] input (as the reference's BatchNorm1d permute does)")
+        return self.fused(input, None)
+
+    def fused(self, input, residual):
+        """Linear unit with `residual` (or None) added after the activation in the same pass."""
         if self.bn_flag:
             out = self.norm1(self.linear(input))
-            return self.act(out) if self.act_flag else out
+            out = self.act(out) if self.act_flag else out
+            return out if residual is None else residual + out
         return ops.linear_bn_act(input, self.linear.weight, self.linear.bias, self.norm2,
-                                 0.2 if self.act_flag else None)
+                                 0.2 if self.act_flag else None, residual=residual)
 
 
 class LocalTrans(nn.Module):
@@ -83,11 +88,11 @@ class LocalTrans(nn.Module):
             context = ops.diffattn_xyz(features, center, idx, self.q.weight, self.q.bias, self.k.weight,
                                        self.k.bias, self.v.weight, self.v.bias)
         else:
-            q = ops.linear(center, self.q.weight, self.q.bias)
-            kv = ops.linear(features, torch.cat((self.k.weight, self.v.weight), 0),
-                            torch.cat((self.k.bias, self.v.bias), 0))
+            # a shift of q (or of every k_j) leaves softmax_j(q - k_j) unchanged: dL/dbq = dL/dbk = 0
+            q = ops.linear(center, self.q.weight, self.q.bias, bias_grad_is_zero=True)
+            kv = ops.linear_kv(features, self.k, self.v)
             context = ops.diffattn(q, kv, idx)
-        return residual + self.ffn(context)
+        return self.ffn.fused(context, residual)
 
 
 class LocalMerge(nn.Module):
@@ -167,7 +172,7 @@ class Fuse(nn.Module):
                 ratio = f[dst].shape[1] // f[src].shape[1]
                 t = upsample(f[src], knn_point(self.knn, xyz[dst], xyz[src])[1], scale_ratio=ratio)
             acc = acc + conv(t)
-        f[dst] = getattr(self, "conv%d" % dst)(acc) + f[dst]
+        f[dst] = getattr(self, "conv%d" % dst).fused(acc, f[dst])
         return tuple(f)
 
 

@@ -40,16 +40,16 @@ def disable_kernel_timing():
 
 
 def kernel_timing_results():
-    """-> {name: {"launches": n, "ms": total_ms, "algo_bytes": total_bytes}} (synchronises)."""
+    """-> {name: {"launches", "ms", "algo_bytes", "algo_flops"}} totals (synchronises)."""
     torch.cuda.synchronize()
     out = {}
     for name, recs in (_TIMERS or {}).items():
-        out[name] = {"launches": len(recs), "ms": sum(a.elapsed_time(b) for a, b, _ in recs),
-                     "algo_bytes": sum(n for _, _, n in recs)}
+        out[name] = {"launches": len(recs), "ms": sum(a.elapsed_time(b) for a, b, _, _ in recs),
+                     "algo_bytes": sum(n for _, _, n, _ in recs), "algo_flops": sum(f for _, _, _, f in recs)}
     return out
 
 
-def _launch(name, *args, algo_bytes=0):
+def _launch(name, *args, algo_bytes=0, algo_flops=0):
     fn = getattr(lib, name)
     recs = _TIMERS.get(name) if _TIMERS is not None else None
     if recs is None:
@@ -59,7 +59,7 @@ def _launch(name, *args, algo_bytes=0):
     e0.record()
     check(fn(*args), name)
     e1.record()
-    recs.append((e0, e1, algo_bytes))
+    recs.append((e0, e1, algo_bytes, algo_flops))
 
 
 # FPS start indices: None = draw from the CPU generator per call (reference behaviour); a hook
@@ -143,7 +143,7 @@ def knn_point(nsample, xyz, new_xyz):
     dist = torch.empty(B, S, nsample, dtype=torch.float32, device=base.device)
     idx = torch.empty(B, S, nsample, dtype=torch.int64, device=base.device)
     _launch("mpa_knn_f32", _p(base), _p(query), B, N, S, C, nsample, _p(dist), _p(idx), _stream(),
-            algo_bytes=B * (4 * C * (S + N) + 12 * S * nsample))
+            algo_bytes=B * (4 * C * (S + N) + 12 * S * nsample), algo_flops=2 * B * S * N * C)
     return dist, idx
 
 
@@ -233,7 +233,8 @@ class _DiffAttn(torch.autograd.Function):
         gq = torch.empty_like(q)
         gkv = torch.zeros_like(kv)
         _launch("mpa_diffattn_bwd_f32", _p(q), _p(kv), _vp(kv.data_ptr() + 4 * C), 2 * C, _p(idx), _p(argk), _p(grad),
-                                       B, N, S, K, C, _p(gq), _p(gkv), _vp(gkv.data_ptr() + 4 * C), 2 * C, _stream())
+                B, N, S, K, C, _p(gq), _p(gkv), _vp(gkv.data_ptr() + 4 * C), 2 * C, _stream(),
+                algo_bytes=B * S * (4 * (3 * C + 2 * K * C + C) + 8 * K + C))
         return gq, gkv, None
 
 
@@ -257,6 +258,7 @@ class _DiffAttnXYZ(torch.autograd.Function):
         _launch("mpa_diffattn_xyz_fwd_f32", _p(xyz), _p(center), _p(idx), *[_p(t) for t in params], B, N, S, K, C,
                                            _p(out), _p(argk), _stream())
         ctx.save_for_backward(xyz, center, idx, argk, *params)
+        ctx.direct = tuple(_direct(t) for t in (Wq, bq, Wk, bk, Wv, bv))
         return out
 
     @staticmethod
@@ -266,11 +268,12 @@ class _DiffAttnXYZ(torch.autograd.Function):
         S, K = idx.shape[1], idx.shape[2]
         C = Wq.shape[0]
         grad = grad.contiguous()
-        gs = [torch.zeros_like(t) for t in (Wq, bq, Wk, bk, Wv, bv)]
+        # the kernel accumulates with atomics: into the cleared flat gradients when installed
+        # (GradReducer direct mode), else into fresh zero tensors
+        gs = [d if d is not None else torch.zeros_like(t) for d, t in zip(ctx.direct, (Wq, bq, Wk, bk, Wv, bv))]
         _launch("mpa_diffattn_xyz_bwd_f32", _p(xyz), _p(center), _p(idx), _p(Wq), _p(bq), _p(Wk), _p(bk), _p(Wv),
-                                           _p(bv), _p(argk), _p(grad), B, N, S, K, C, *[_p(g) for g in gs],
-                                           _stream())
-        return (None, None, None) + tuple(gs)
+                _p(bv), _p(argk), _p(grad), B, N, S, K, C, *[_p(g) for g in gs], _stream())
+        return (None, None, None) + tuple(None if d is not None else g for d, g in zip(ctx.direct, gs))
 
 
 def diffattn_xyz(xyz, center, idx, Wq, bq, Wk, bk, Wv, bv):
@@ -369,27 +372,58 @@ def _gemm(A, lda, tA, Bm, ldb, tB, bias, C, ldc, M, N, K, accumulate=0, tile_sta
             ws = _workspace(C.device, splits * M * N * 4)
             ws_bytes = ws.numel() * 4
     _launch("mpa_gemm_f32", _p(A), lda, tA, _p(Bm), ldb, tB, _p(bias), _p(C), ldc, M, N, K, accumulate,
-            _p(tile_stats), _p(ws), ws_bytes, _stream(), algo_bytes=4 * (M * K + N * K + M * N))
+            _p(tile_stats), _p(ws), ws_bytes, _stream(), algo_bytes=4 * (M * K + N * K + M * N),
+            algo_flops=2 * M * N * K)
 
 
-def _col_sum(x2d):
+_ZEROS = {}
+
+
+def _zeros_like_cached(device, n):
+    """A shared read-only zero vector (gradients that are identically zero); autograd never
+    writes into a returned gradient it does not own."""
+    key = (device.index, n)
+    z = _ZEROS.get(key)
+    if z is None:
+        z = _ZEROS[key] = torch.zeros(n, dtype=torch.float32, device=device)
+    return z
+
+
+def _col_sum(x2d, ld=None):
     M, C = x2d.shape
-    st = torch.zeros(2, C, dtype=torch.float32, device=x2d.device)
-    _launch("mpa_col_stats_f32", _p(x2d), M, C, _p(st[0]), _p(st[1]), _stream())
-    return st[0]
+    out = torch.zeros(C, dtype=torch.float32, device=x2d.device)
+    _launch("mpa_col_sum_f32", _p(x2d), M, C, C if ld is None else ld, _p(out), _stream())
+    return out
+
+
+def _col_sum_into(x2d, out, ld=None):
+    """out[C] += column sums of x2d (out is a cleared flat-gradient view)."""
+    M, C = x2d.shape
+    _launch("mpa_col_sum_f32", _p(x2d), M, C, C if ld is None else ld, _p(out), _stream())
+
+
+def _direct(t):
+    """Flat-gradient view installed by distributed.GradReducer(direct=True): backward kernels write
+    the parameter's gradient straight into it (the parameter is used once per step and the flat
+    buffers are cleared at the start of the step), and autograd gets None for that input."""
+    return getattr(t, "_mpa_grad_buf", None) if t is not None else None
 
 
 class _Linear(torch.autograd.Function):
-    """y[M,N] = x[M,K] W[N,K]^T + b on the fp32-MFMA GEMM; backward = two more GEMMs."""
+    """y[M,N] = x[M,K] W[N,K]^T + b on the fp32-MFMA GEMM; backward = two more GEMMs.
+    bias_grad_is_zero: the caller knows the bias gradient vanishes identically (q / k projections
+    of the difference attention: a shift of q or of every k_j leaves the softmax unchanged)."""
 
     @staticmethod
-    def forward(ctx, x, W, b):
+    def forward(ctx, x, W, b, bias_grad_is_zero):
         M, K = x.shape
         N = W.shape[0]
         y = torch.empty(M, N, dtype=torch.float32, device=x.device)
         _gemm(x, K, 0, W, K, 1, b, y, N, M, N, K)
         ctx.save_for_backward(x, W)
         ctx.has_bias = b is not None
+        ctx.zero_bias = bool(bias_grad_is_zero)
+        ctx.direct = (_direct(W), _direct(b))
         return y
 
     @staticmethod
@@ -398,33 +432,93 @@ class _Linear(torch.autograd.Function):
         M, K = x.shape
         N = W.shape[0]
         gy = gy.contiguous()
+        dW, db = ctx.direct
         gx = gW = gb = None
         if ctx.needs_input_grad[0]:
             gx = torch.empty(M, K, dtype=torch.float32, device=x.device)
             _gemm(gy, N, 0, W, K, 0, None, gx, K, M, K, N)            # gy [M,N] @ W [N,K]
         if ctx.needs_input_grad[1]:
-            gW = torch.empty(N, K, dtype=torch.float32, device=x.device)
+            gW = dW if dW is not None else torch.empty(N, K, dtype=torch.float32, device=x.device)
             _gemm(gy, N, 1, x, K, 0, None, gW, K, N, K, M)            # gy^T [N,M] @ x [M,K]
+            if dW is not None:
+                gW = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = _col_sum(gy)
-        return gx, gW, gb
+            if ctx.zero_bias:
+                gb = None if db is not None else _zeros_like_cached(x.device, N)
+            elif db is not None:
+                _col_sum_into(gy, db)
+            else:
+                gb = _col_sum(gy)
+        return gx, gW, gb, None
 
 
-def linear(x, weight, bias):
+def linear(x, weight, bias, bias_grad_is_zero=False):
     """y = x W^T + b over the last dimension (nn.Linear), any leading shape."""
     _dev(x, weight)
     lead = x.shape[:-1]
-    y = _Linear.apply(_f32(x).reshape(-1, x.shape[-1]), _f32(weight), bias)
+    y = _Linear.apply(_f32(x).reshape(-1, x.shape[-1]), _f32(weight), bias, bias_grad_is_zero)
     return y.view(*lead, weight.shape[0])
 
 
-class _LinearBNAct(torch.autograd.Function):
-    """Linear -> BatchNorm1d over the rows -> LeakyReLU, as one unit: the GEMM epilogue yields
-    the batch statistics, one elementwise kernel normalises + activates (and updates the
-    running statistics), backward is reduce + apply + two GEMMs."""
+class _LinearKV(torch.autograd.Function):
+    """kv[M, 2C] = x [Wk; Wv]^T + [bk; bv]: the key and value projections of LocalTrans' feature
+    branch as one GEMM (keys in columns [0,C), values in [C,2C)), without materialising the
+    concatenated parameters in autograd: weight gradients are two GEMMs on the two column
+    blocks, dbk = 0 identically (see _Linear), dbv = column sums of the value block."""
 
     @staticmethod
-    def forward(ctx, x, W, b, gamma, beta, running_mean, running_var, training, momentum, eps, slope):
+    def forward(ctx, x, Wk, bk, Wv, bv):
+        M, K = x.shape
+        C = Wk.shape[0]
+        Wkv = torch.cat((Wk, Wv), 0)
+        bkv = torch.cat((bk, bv), 0)
+        kv = torch.empty(M, 2 * C, dtype=torch.float32, device=x.device)
+        _gemm(x, K, 0, Wkv, K, 1, bkv, kv, 2 * C, M, 2 * C, K)
+        ctx.save_for_backward(x, Wkv)
+        ctx.direct = (_direct(Wk), _direct(bk), _direct(Wv), _direct(bv))
+        return kv
+
+    @staticmethod
+    def backward(ctx, gkv):
+        x, Wkv = ctx.saved_tensors
+        M, K = x.shape
+        C = Wkv.shape[0] // 2
+        dev = x.device
+        gkv = gkv.contiguous()
+        dWk, dbk, dWv, dbv = ctx.direct
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty(M, K, dtype=torch.float32, device=dev)
+            _gemm(gkv, 2 * C, 0, Wkv, K, 0, None, gx, K, M, K, 2 * C)
+        gv_view = gkv[:, C:]
+        gWk = dWk if dWk is not None else torch.empty(C, K, dtype=torch.float32, device=dev)
+        gWv = dWv if dWv is not None else torch.empty(C, K, dtype=torch.float32, device=dev)
+        _gemm(gkv, 2 * C, 1, x, K, 0, None, gWk, K, C, K, M)                     # gk^T x
+        _gemm(gv_view, 2 * C, 1, x, K, 0, None, gWv, K, C, K, M)                 # gv^T x
+        if dbv is not None:
+            _col_sum_into(gv_view, dbv, ld=2 * C)
+            gbv = None
+        else:
+            gbv = _col_sum(gv_view, ld=2 * C)
+        gbk = None if dbk is not None else _zeros_like_cached(dev, C)
+        return (gx, None if dWk is not None else gWk, gbk, None if dWv is not None else gWv, gbv)
+
+
+def linear_kv(x, k_lin, v_lin):
+    """Projected keys | values [.., 2C] of LocalTrans' feature branch from the two nn.Linear."""
+    _dev(x, k_lin.weight)
+    lead = x.shape[:-1]
+    kv = _LinearKV.apply(_f32(x).reshape(-1, x.shape[-1]), k_lin.weight, k_lin.bias, v_lin.weight, v_lin.bias)
+    return kv.view(*lead, kv.shape[-1])
+
+
+class _LinearBNAct(torch.autograd.Function):
+    """Linear -> BatchNorm1d over the rows -> LeakyReLU (+ residual), as one unit: the GEMM epilogue
+    yields the batch statistics, one elementwise kernel normalises + activates (+ adds the
+    residual), backward is reduce + apply + two GEMMs."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, gamma, beta, running_mean, running_var, residual, training, momentum, eps, slope):
         M, K = x.shape
         N = W.shape[0]
         dev = x.device
@@ -433,46 +527,72 @@ class _LinearBNAct(torch.autograd.Function):
         _gemm(x, K, 0, W, K, 1, b, y, N, M, N, K, 0, stats)
         out = torch.empty(M, N, dtype=torch.float32, device=dev)
         saved = torch.empty(2, N, dtype=torch.float32, device=dev)
+        direct = (_direct(W), _direct(b), _direct(gamma), _direct(beta))
+        need = any(ctx.needs_input_grad)
+        own_sums = need and (direct[2] is None or direct[3] is None)
+        # sums: the [2][N] accumulator of backward's channel reductions, cleared here for free
+        sums = torch.empty(2, N, dtype=torch.float32, device=dev) if own_sums else None
         _launch("mpa_bn_finalize_f32", _p(stats), M, N, _p(running_mean), _p(running_var), int(training),
-                float(momentum), float(eps), _p(saved), _stream())
-        _launch("mpa_bn_act_fwd_f32", _p(y), _p(saved), _p(gamma), _p(beta), float(slope), M, N, _p(out), _stream())
-        ctx.save_for_backward(x, W, y, gamma, beta, saved)
-        ctx.cfg = (bool(training), float(slope), b is not None)
+                float(momentum), float(eps), _p(saved), _p(sums), 2 * N, _stream())
+        _launch("mpa_bn_act_fwd_f32", _p(y), _p(saved), _p(gamma), _p(beta), _p(residual), float(slope), M, N,
+                _p(out), _stream())
+        ctx.save_for_backward(x, W, y, gamma, beta, saved, sums)
+        ctx.cfg = (bool(training), float(slope), b is not None, residual is not None)
+        ctx.direct = direct
+        ctx.ran_backward = False
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        x, W, y, gamma, beta, saved = ctx.saved_tensors
-        training, slope, has_bias = ctx.cfg
+        x, W, y, gamma, beta, saved, sums = ctx.saved_tensors
+        training, slope, has_bias, has_res = ctx.cfg
+        dW, db, dgamma, dbeta = ctx.direct
         M, K = x.shape
         N = W.shape[0]
         dev = x.device
         gout = gout.contiguous()
-        sums = torch.zeros(2, N, dtype=torch.float32, device=dev)
+        if sums is None:
+            sum_g, sum_gx = dbeta, dgamma              # accumulate straight into the flat gradients
+        else:
+            if ctx.ran_backward:        # double backward through the same node: accumulator is dirty
+                sums = torch.zeros(2, N, dtype=torch.float32, device=dev)
+            sum_g, sum_gx = sums[0], sums[1]
+        ctx.ran_backward = True
         _launch("mpa_bn_act_bwd_reduce_f32", _p(y), _p(gout), _p(saved[0]), _p(saved[1]), _p(gamma), _p(beta), slope,
-                M, N, _p(sums[0]), _p(sums[1]), _stream())
+                M, N, _p(sum_g), _p(sum_gx), _stream())
         gy = torch.empty(M, N, dtype=torch.float32, device=dev)
         _launch("mpa_bn_act_bwd_apply_f32", _p(y), _p(gout), _p(saved[0]), _p(saved[1]), _p(gamma), _p(beta),
-                _p(sums[0]), _p(sums[1]), slope, int(training), M, N, _p(gy), _stream())
+                _p(sum_g), _p(sum_gx), slope, int(training), M, N, _p(gy), _stream())
         gx = gW = gb = None
         if ctx.needs_input_grad[0]:
             gx = torch.empty(M, K, dtype=torch.float32, device=dev)
             _gemm(gy, N, 0, W, K, 0, None, gx, K, M, K, N)
         if ctx.needs_input_grad[1]:
-            gW = torch.empty(N, K, dtype=torch.float32, device=dev)
+            gW = dW if dW is not None else torch.empty(N, K, dtype=torch.float32, device=dev)
             _gemm(gy, N, 1, x, K, 0, None, gW, K, N, K, M)
+            if dW is not None:
+                gW = None
         if has_bias and ctx.needs_input_grad[2]:
             # In front of a train-mode BatchNorm the bias gradient is identically zero (the batch
             # mean removes any constant shift); the reference's value there is fp32 rounding noise.
-            gb = torch.zeros(N, dtype=torch.float32, device=dev) if training else _col_sum(gy)
-        return gx, gW, gb, sums[1], sums[0], None, None, None, None, None, None
+            if training:
+                gb = None if db is not None else _zeros_like_cached(dev, N)
+            elif db is not None:
+                _col_sum_into(gy, db)
+            else:
+                gb = _col_sum(gy)
+        ggamma = None if sums is None else sum_gx
+        gbeta = None if sums is None else sum_g
+        gres = gout if has_res else None
+        return gx, gW, gb, ggamma, gbeta, None, None, gres, None, None, None, None
 
 
-def linear_bn_act(x, weight, bias, bn, slope):
+def linear_bn_act(x, weight, bias, bn, slope, residual=None):
     """The reference's Linear unit (modules/pointnet2_utils.py:413-425): affine, BatchNorm1d
     over the B*S rows (batch statistics in training, running statistics in eval; `bn` is the
     nn.BatchNorm1d holding gamma/beta/running stats), LeakyReLU(slope) unless slope is None.
-    x is [B,S,C] or [M,C]."""
+    x is [B,S,C] or [M,C].  residual (same shape as the output) is added after the activation in
+    the same kernel (LocalTrans' `residual + ffn(context)`, Fuse's `conv(x) + f`)."""
     _dev(x, weight)
     lead = x.shape[:-1]
     x2 = _f32(x).reshape(-1, x.shape[-1])
@@ -482,6 +602,7 @@ def linear_bn_act(x, weight, bias, bn, slope):
     if training and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
     momentum = 0.1 if bn.momentum is None else bn.momentum
-    out = _LinearBNAct.apply(x2, _f32(weight), bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, training,
-                             momentum, bn.eps, 1.0 if slope is None else slope)
+    res2 = None if residual is None else _f32(residual).reshape(-1, weight.shape[0])
+    out = _LinearBNAct.apply(x2, _f32(weight), bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, res2,
+                             training, momentum, bn.eps, 1.0 if slope is None else slope)
     return out.view(*lead, weight.shape[0])

@@ -60,7 +60,7 @@ class GraphedTrainStep:
         self.model, self.loss_fn, self.opt = model, loss_fn, optimizer
         self.static = [t.clone() for t in example_batch]
         self.feeder = FpsStartFeeder()
-        self.reducer = GradReducer(model, bucket_bytes=bucket_bytes)
+        self.reducer = GradReducer(model, bucket_bytes=bucket_bytes, direct=True)
         self.reducer.overlap = False
         ops.set_fps_start_hook(self.feeder)
 

@@ -1,0 +1,33 @@
+"""Which ATen ops (not libmpa kernels) still launch kernels in one eager train step, and from where."""
+import os, sys, argparse, collections
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import mpa_amd
+from mpa_amd import ops
+from mpa_amd.models.repsurf.repsurf_ssg_umb import Model, SmoothClsLoss
+from mpa_amd.distributed import GradReducer
+sys.argv = [sys.argv[0]]
+from bench import synthetic_batch
+dev = torch.device("cuda")
+torch.manual_seed(0)
+args = argparse.Namespace(num_point=1024, return_dist=True, cuda_ops=True, num_class=40)
+model = Model(args).to(dev).train()
+crit = SmoothClsLoss()
+x, y = synthetic_batch(64, 1234, dev)
+red = GradReducer(model); red.overlap = False
+def step():
+    red.zero_grad(); loss = crit(model(x), y); loss.backward(); red.all_reduce()
+for _ in range(3): step()
+torch.cuda.synchronize()
+from torch.profiler import profile, ProfilerActivity
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=False) as prof:
+    step(); torch.cuda.synchronize()
+rows = []
+for e in prof.key_averages():
+    dt = getattr(e, "device_time_total", None) or getattr(e, "cuda_time_total", 0)
+    if dt > 0 and e.key.startswith("aten::"):
+        rows.append((dt, e.count, e.key))
+rows.sort(reverse=True)
+for dt, cnt, key in rows[:25]:
+    print("%9.1f us %5d calls  %s" % (dt, cnt, key))
