@@ -144,8 +144,7 @@ def main():
     else:
         # the whole forward+backward is one HIP graph; all-reduce + (graphed) Adam follow it
         from mpa_amd.runtime import GraphedTrainStep
-        opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True)
-        graphed = GraphedTrainStep(model, crit, opt, (x, y))
+        graphed = GraphedTrainStep(model, crit, (x, y), lr=1e-3)      # optim.FlatAdam on the flat buckets
 
         def step():
             return graphed(x, y)

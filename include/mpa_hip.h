@@ -177,6 +177,15 @@ int mpa_three_interp_fwd_f32(const float *points2, const int64_t *idx, const flo
 int mpa_three_interp_bwd_f32(const float *grad_out, const int64_t *idx, const float *dist,
                              int B, int Nq, int Nb, int C, float *grad_points2, void *stream);
 
+/* ---- optimizer step over flat buckets (the training loop of tool/train_cls_scanobjectnn.py:205-216
+ * uses torch.optim.Adam; gradients here live in a few flat buffers, so one elementwise pass per
+ * bucket replaces ~300 per-parameter launches).  torch.optim.Adam arithmetic, no amsgrad.
+ * `step` is a device scalar holding the (already advanced) step count t. */
+int mpa_scalar_add_f32(float *x, float a, void *stream);
+int mpa_adam_step_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long long n,
+                      float lr, float beta1, float beta2, float eps, float weight_decay,
+                      const float *step, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

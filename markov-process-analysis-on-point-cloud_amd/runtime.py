@@ -19,6 +19,11 @@ from . import ops
 from .distributed import GradReducer, is_dist, world_size
 
 
+import os
+
+_SKIP_OPT = bool(os.environ.get("MPA_DEBUG_SKIP_OPT"))      # profiling aid: replay fwd+bwd only
+
+
 class FpsStartFeeder:
     def __init__(self):
         self.slots = []
@@ -50,14 +55,18 @@ class GraphedTrainStep:
     """forward + loss + backward captured as one HIP graph, gradient all-reduce (if distributed)
     and the optimizer step (a second graph) after it.
 
-        step = GraphedTrainStep(model, loss_fn, optimizer, (points, labels))
+        step = GraphedTrainStep(model, loss_fn, (points, labels), lr=1e-3)
         loss = step(points, labels)        # copies the batch into the static buffers, replays
 
-    `optimizer` must be capturable (torch.optim.Adam(..., capturable=True)).  Gradients live in
-    the GradReducer's flat buckets; BatchNorm statistics stay per rank."""
+    Gradients live in the GradReducer's flat buckets, written there directly by the backward
+    kernels; the default optimizer is optim.FlatAdam (one launch per bucket).  A torch optimizer
+    can be passed instead (`optimizer=`; it must be capturable).  BatchNorm statistics stay per
+    rank."""
 
-    def __init__(self, model, loss_fn, optimizer, example_batch, warmup=2, bucket_bytes=16 << 20):
-        self.model, self.loss_fn, self.opt = model, loss_fn, optimizer
+    def __init__(self, model, loss_fn, example_batch, optimizer=None, lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
+                 weight_decay=0.0, warmup=2, bucket_bytes=16 << 20):
+        from .optim import FlatAdam
+        self.model, self.loss_fn = model, loss_fn
         self.static = [t.clone() for t in example_batch]
         self.feeder = FpsStartFeeder()
         self.reducer = GradReducer(model, bucket_bytes=bucket_bytes, direct=True)
@@ -67,7 +76,11 @@ class GraphedTrainStep:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            for _ in range(max(1, warmup)):          # eager passes: build buckets, warm allocator
+            self._fwd_bwd()                          # discovers the live parameters, builds buckets
+            self.reducer.all_reduce()
+            self.opt = optimizer if optimizer is not None else FlatAdam(self.reducer, lr, betas, eps, weight_decay)
+            self.opt.step()
+            for _ in range(max(0, warmup - 1)):      # eager passes: warm allocator / workspaces
                 self._fwd_bwd()
                 self.reducer.all_reduce()
                 self.opt.step()
@@ -96,7 +109,8 @@ class GraphedTrainStep:
         self.graph.replay()
         if is_dist() and world_size() > 1:
             self.reducer.all_reduce()
-        self.opt_graph.replay()
+        if not _SKIP_OPT:
+            self.opt_graph.replay()
         return self.loss
 
     def close(self):
