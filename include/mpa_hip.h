@@ -120,12 +120,14 @@ int mpa_diffattn_xyz_bwd_f32(const float *xyz, const float *center, const int64_
  *   64-row tile and column the sum and the sum of squared deviations from the tile mean -- the
  *   BatchNorm batch statistics in Chan's pairwise form (no atomics: deterministic; no
  *   E[y^2]-E[y]^2 cancellation).  mpa_bn_finalize_f32 combines them.
+ *   a_col_sum (optional, [M], cleared by the caller): receives sum_k op(A)[m][k] with float atomics
+ *   -- the bias gradient, for free, when op(A) = dY^T in the weight-gradient product.
  *   workspace (optional, 16-B aligned): scratch for split-K partial tiles (weight gradients have
  *   K = B*S rows and a tiny output); without it split-K falls back to float atomics into C.
  *   accumulate != 0 adds into C. */
 int mpa_gemm_f32(const float *A, int lda, int transA, const float *B, int ldb, int transB,
                  const float *bias, float *C, int ldc, int M, int N, int K, int accumulate,
-                 float *tile_stats, float *workspace, size_t workspace_bytes, void *stream);
+                 float *tile_stats, float *a_col_sum, float *workspace, size_t workspace_bytes, void *stream);
 /* tile statistics (same format as the GEMM epilogue's) of an existing tensor x [M,C]. */
 int mpa_tile_stats_f32(const float *x, int M, int C, float *tile_stats, void *stream);
 /* per-column sum and sum of squares of x [M,C] -> col_sum, col_sumsq [C] (caller zeroes). */
@@ -134,10 +136,11 @@ int mpa_col_stats_f32(const float *x, int M, int C, float *col_sum, float *col_s
  * from tile_stats over the M rows (biased variance), and running_mean/var (may be NULL) are
  * updated with `momentum` (unbiased variance) as nn.BatchNorm1d does; training == 0: from the
  * running statistics (tile_stats ignored).  zero_buf (optional): zero_count floats cleared by the
- * same launch -- the [2][C] accumulator that mpa_bn_act_bwd_reduce_f32 later adds into. */
+ * same launch -- the [2][C] accumulator that mpa_bn_act_bwd_reduce_f32 later adds into.
+ * num_batches_tracked (optional): nn.BatchNorm1d's int64 counter, incremented when training. */
 int mpa_bn_finalize_f32(const float *tile_stats, int M, int C, float *running_mean, float *running_var,
                         int training, float momentum, float eps, float *save_mean_invstd, float *zero_buf,
-                        int zero_count, void *stream);
+                        int zero_count, int64_t *num_batches_tracked, void *stream);
 /* y = residual + leaky_relu((x - mean[c]) * invstd[c] * gamma[c] + beta[c], slope) over [M,C]
  * (slope = 1: no activation; residual may be NULL -- it is LocalTrans' `residual + ffn(context)`,
  * modules/pointnet2_utils.py:572, fused into the same pass).  In place allowed (y == x). */

@@ -36,9 +36,9 @@ SIGNATURES = {
     "mpa_diffattn_bwd_f32": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp],
     "mpa_diffattn_xyz_fwd_f32": [_vp] * 9 + [_i] * 5 + [_vp, _vp, _vp],
     "mpa_diffattn_xyz_bwd_f32": [_vp] * 11 + [_i] * 5 + [_vp] * 6 + [_vp],
-    "mpa_gemm_f32": [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, ctypes.c_size_t, _vp],
+    "mpa_gemm_f32": [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, ctypes.c_size_t, _vp],
     "mpa_tile_stats_f32": [_vp, _i, _i, _vp, _vp],
-    "mpa_bn_finalize_f32": [_vp, _i, _i, _vp, _vp, _i, _f, _f, _vp, _vp, _i, _vp],
+    "mpa_bn_finalize_f32": [_vp, _i, _i, _vp, _vp, _i, _f, _f, _vp, _vp, _i, _vp, _vp],
     "mpa_col_stats_f32": [_vp, _i, _i, _vp, _vp, _vp],
     "mpa_bn_act_fwd_f32": [_vp, _vp, _vp, _vp, _vp, _f, _i, _i, _vp, _vp],
     "mpa_col_sum_f32": [_vp, _i, _i, _i, _vp, _vp],

@@ -37,7 +37,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const float *__restrict__ A
                                                      const float *__restrict__ B, int ldb,
                                                      const float *__restrict__ bias, float *__restrict__ C, int ldc,
                                                      int M, int N, int K, int kchunk, int out_mode, int vecA,
-                                                     int vecB, float *__restrict__ tile_stats, float *__restrict__ zero_c)
+                                                     int vecB, float *__restrict__ tile_stats, float *__restrict__ zero_c,
+                                                     float *__restrict__ a_col_sum)
 {
     // out_mode 0: C = result (+bias);  1: atomicAdd into C;  2: split-K partial slab
     //             C + blockIdx.z*M*ldc (plain stores, summed by splitk_reduce_kernel).
@@ -140,6 +141,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const float *__restrict__ A
         }
     };
 
+    float asum0 = 0.f, asum1 = 0.f;          // sum over k of this lane's A operands (a_col_sum)
     floatx16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -168,9 +170,23 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const float *__restrict__ A
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            asum0 += a0;
+            asum1 += a1;
         }
         if (s + 1 < nslab) store_slab(lds + ((s + 1) & 1) * BUF);
         __syncthreads();
+    }
+
+    // ---- optional: column sums of op(A) over this workgroup's K range, i.e. sum_k A^T[k][m] -- the
+    // bias gradient when A = dY^T in the weight-gradient product.  Only the n-tile 0 workgroups
+    // contribute (every n-tile sees the same A rows); one float atomic per (workgroup, m).
+    if (a_col_sum != nullptr && n0 == 0) {
+        asum0 += __shfl_xor(asum0, 32, 64);
+        asum1 += __shfl_xor(asum1, 32, 64);
+        if (half == 0) {
+            if (m0 + l31 < M) atomicAdd(a_col_sum + m0 + l31, asum0);
+            if (m0 + 32 + l31 < M) atomicAdd(a_col_sum + m0 + 32 + l31, asum1);
+        }
     }
 
     // ---- sum the 4 waves' partial tiles through LDS: red[wave][row][col], 64 x 64 each
@@ -312,13 +328,13 @@ constexpr size_t gemm_lds_bytes(bool, bool) { return sizeof(float) * 2 * KS * (T
 template <bool TA, bool TB>
 int launch_gemm(const float *A, int lda, const float *B, int ldb, const float *bias, float *C, int ldc, int M, int N,
                 int K, int splits, int kchunk, int out_mode, int vecA, int vecB, float *stats, float *zero_c,
-                hipStream_t st)
+                float *a_col_sum, hipStream_t st)
 {
     constexpr size_t lds = gemm_lds_bytes(TA, TB);
     static_assert(lds >= sizeof(float) * 4 * TS * TS && lds <= 64 * 1024, "reduction region fits, no opt-in");
     dim3 grid(mpa_ceil_div(M, TS) * mpa_ceil_div(N, TS), 1, splits);
     hipLaunchKernelGGL((gemm_kernel<TA, TB>), grid, dim3(NT), lds, st, A, lda, B, ldb, bias, C, ldc, M, N, K, kchunk,
-                       out_mode, vecA, vecB, stats, zero_c);
+                       out_mode, vecA, vecB, stats, zero_c, a_col_sum);
     return MPA_OK;
 }
 
@@ -396,7 +412,8 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float *__restri
                                                            float *__restrict__ running_mean,
                                                            float *__restrict__ running_var, int training,
                                                            float momentum, float eps, float *__restrict__ save,
-                                                           float *__restrict__ zero_me, int zero_n)
+                                                           float *__restrict__ zero_me, int zero_n,
+                                                           long long *__restrict__ num_batches_tracked)
 {
     // 1024 lanes = 16 tile-groups x 64 channels: up to 1024 tiles per channel are summed as 16
     // interleaved partial chains (4 independent loads in flight each), then combined in LDS in a
@@ -405,8 +422,10 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float *__restri
     __shared__ float mean_s[64];
     const int tid = threadIdx.x, cl = tid & 63, g = tid >> 6;
     const int c = blockIdx.x * 64 + cl;
-    if (blockIdx.x == 0)
+    if (blockIdx.x == 0) {
         for (int i = tid; i < zero_n; i += 1024) zero_me[i] = 0.f;     // scratch the backward pass accumulates into
+        if (tid == 0 && training && num_batches_tracked != nullptr) *num_batches_tracked += 1;
+    }
     if (!training) {
         if (g == 0 && c < C) {
             save[c] = running_mean[c];
@@ -654,7 +673,8 @@ static int launch_col_stats(const float *x, int M, int C, float *col_sum, float 
 
 extern "C" int mpa_gemm_f32(const float *A, int lda, int transA, const float *B, int ldb, int transB,
                             const float *bias, float *C, int ldc, int M, int N, int K, int accumulate,
-                            float *tile_stats, float *workspace, size_t workspace_bytes, void *stream)
+                            float *tile_stats, float *a_col_sum, float *workspace, size_t workspace_bytes,
+                            void *stream)
 {
     MPA_CLEAR_ERROR();
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || lda <= 0 || ldb <= 0 || ldc < N) return MPA_EINVAL;
@@ -702,16 +722,16 @@ extern "C" int mpa_gemm_f32(const float *A, int lda, int transA, const float *B,
     int rc;
     if (transA && transB)
         rc = launch_gemm<true, true>(A, lda, B, ldb, bias, dst, ldc, M, N, K, splits, kchunk, out_mode, vecA, vecB,
-                                     stats, zero_c, st);
+                                     stats, zero_c, a_col_sum, st);
     else if (transA)
         rc = launch_gemm<true, false>(A, lda, B, ldb, bias, dst, ldc, M, N, K, splits, kchunk, out_mode, vecA, vecB,
-                                      stats, zero_c, st);
+                                      stats, zero_c, a_col_sum, st);
     else if (transB)
         rc = launch_gemm<false, true>(A, lda, B, ldb, bias, dst, ldc, M, N, K, splits, kchunk, out_mode, vecA, vecB,
-                                      stats, zero_c, st);
+                                      stats, zero_c, a_col_sum, st);
     else
         rc = launch_gemm<false, false>(A, lda, B, ldb, bias, dst, ldc, M, N, K, splits, kchunk, out_mode, vecA, vecB,
-                                       stats, zero_c, st);
+                                       stats, zero_c, a_col_sum, st);
     if (rc != MPA_OK) return rc;
     if (reduce_after) {
         const int gx = mpa_ceil_div((long long)mn, 256);
@@ -759,7 +779,7 @@ extern "C" int mpa_tile_stats_f32(const float *x, int M, int C, float *tile_stat
 
 extern "C" int mpa_bn_finalize_f32(const float *tile_stats, int M, int C, float *running_mean, float *running_var,
                                    int training, float momentum, float eps, float *save_mean_invstd, float *zero_buf,
-                                   int zero_count, void *stream)
+                                   int zero_count, int64_t *num_batches_tracked, void *stream)
 {
     MPA_CLEAR_ERROR();
     if (!save_mean_invstd || M <= 0 || C <= 0) return MPA_EINVAL;
@@ -767,7 +787,7 @@ extern "C" int mpa_bn_finalize_f32(const float *tile_stats, int M, int C, float 
     if (!training && (!running_mean || !running_var)) return MPA_EINVAL;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(mpa_ceil_div(C, 64)), dim3(1024), 0, (hipStream_t)stream, tile_stats, M,
                        C, running_mean, running_var, training, momentum, eps, save_mean_invstd, zero_buf,
-                       zero_buf ? zero_count : 0);
+                       zero_buf ? zero_count : 0, reinterpret_cast<long long *>(num_batches_tracked));
     MPA_LAUNCH_CHECK();
     return MPA_OK;
 }

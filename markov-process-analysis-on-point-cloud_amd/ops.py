@@ -363,7 +363,7 @@ def _workspace(device, nbytes):
     return ws
 
 
-def _gemm(A, lda, tA, Bm, ldb, tB, bias, C, ldc, M, N, K, accumulate=0, tile_stats=None):
+def _gemm(A, lda, tA, Bm, ldb, tB, bias, C, ldc, M, N, K, accumulate=0, tile_stats=None, a_col_sum=None):
     ws, ws_bytes = None, 0
     ntiles = ((M + 63) // 64) * ((N + 63) // 64)
     if ntiles < 256 and K >= 512 and ldc == N:          # split-K partial tiles (see mpa_gemm_f32)
@@ -372,7 +372,7 @@ def _gemm(A, lda, tA, Bm, ldb, tB, bias, C, ldc, M, N, K, accumulate=0, tile_sta
             ws = _workspace(C.device, splits * M * N * 4)
             ws_bytes = ws.numel() * 4
     _launch("mpa_gemm_f32", _p(A), lda, tA, _p(Bm), ldb, tB, _p(bias), _p(C), ldc, M, N, K, accumulate,
-            _p(tile_stats), _p(ws), ws_bytes, _stream(), algo_bytes=4 * (M * K + N * K + M * N),
+            _p(tile_stats), _p(a_col_sum), _p(ws), ws_bytes, _stream(), algo_bytes=4 * (M * K + N * K + M * N),
             algo_flops=2 * M * N * K)
 
 
@@ -437,18 +437,23 @@ class _Linear(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = torch.empty(M, K, dtype=torch.float32, device=x.device)
             _gemm(gy, N, 0, W, K, 0, None, gx, K, M, K, N)            # gy [M,N] @ W [N,K]
+        want_b = ctx.has_bias and ctx.needs_input_grad[2] and not ctx.zero_bias
+        gb_buf = None
+        if want_b:
+            gb_buf = db if db is not None else torch.zeros(N, dtype=torch.float32, device=x.device)
         if ctx.needs_input_grad[1]:
             gW = dW if dW is not None else torch.empty(N, K, dtype=torch.float32, device=x.device)
-            _gemm(gy, N, 1, x, K, 0, None, gW, K, N, K, M)            # gy^T [N,M] @ x [M,K]
+            # gy^T [N,M] @ x [M,K]; the bias gradient (column sums of gy) rides along
+            _gemm(gy, N, 1, x, K, 0, None, gW, K, N, K, M, a_col_sum=gb_buf)
             if dW is not None:
                 gW = None
+        elif want_b:
+            _col_sum_into(gy, gb_buf)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             if ctx.zero_bias:
                 gb = None if db is not None else _zeros_like_cached(x.device, N)
-            elif db is not None:
-                _col_sum_into(gy, db)
             else:
-                gb = _col_sum(gy)
+                gb = None if db is not None else gb_buf
         return gx, gW, gb, None
 
 
@@ -494,12 +499,11 @@ class _LinearKV(torch.autograd.Function):
         gWk = dWk if dWk is not None else torch.empty(C, K, dtype=torch.float32, device=dev)
         gWv = dWv if dWv is not None else torch.empty(C, K, dtype=torch.float32, device=dev)
         _gemm(gkv, 2 * C, 1, x, K, 0, None, gWk, K, C, K, M)                     # gk^T x
-        _gemm(gv_view, 2 * C, 1, x, K, 0, None, gWv, K, C, K, M)                 # gv^T x
+        # gv^T x; its A operand's column sums are dbv (accumulated by the same kernel)
+        gbv = dbv if dbv is not None else torch.zeros(C, dtype=torch.float32, device=dev)
+        _gemm(gv_view, 2 * C, 1, x, K, 0, None, gWv, K, C, K, M, a_col_sum=gbv)
         if dbv is not None:
-            _col_sum_into(gv_view, dbv, ld=2 * C)
             gbv = None
-        else:
-            gbv = _col_sum(gv_view, ld=2 * C)
         gbk = None if dbk is not None else _zeros_like_cached(dev, C)
         return (gx, None if dWk is not None else gWk, gbk, None if dWv is not None else gWv, gbv)
 
@@ -518,7 +522,7 @@ class _LinearBNAct(torch.autograd.Function):
     residual), backward is reduce + apply + two GEMMs."""
 
     @staticmethod
-    def forward(ctx, x, W, b, gamma, beta, running_mean, running_var, residual, training, momentum, eps, slope):
+    def forward(ctx, x, W, b, gamma, beta, running_mean, running_var, nbt, residual, training, momentum, eps, slope):
         M, K = x.shape
         N = W.shape[0]
         dev = x.device
@@ -533,7 +537,7 @@ class _LinearBNAct(torch.autograd.Function):
         # sums: the [2][N] accumulator of backward's channel reductions, cleared here for free
         sums = torch.empty(2, N, dtype=torch.float32, device=dev) if own_sums else None
         _launch("mpa_bn_finalize_f32", _p(stats), M, N, _p(running_mean), _p(running_var), int(training),
-                float(momentum), float(eps), _p(saved), _p(sums), 2 * N, _stream())
+                float(momentum), float(eps), _p(saved), _p(sums), 2 * N, _p(nbt), _stream())
         _launch("mpa_bn_act_fwd_f32", _p(y), _p(saved), _p(gamma), _p(beta), _p(residual), float(slope), M, N,
                 _p(out), _stream())
         ctx.save_for_backward(x, W, y, gamma, beta, saved, sums)
@@ -584,7 +588,7 @@ class _LinearBNAct(torch.autograd.Function):
         ggamma = None if sums is None else sum_gx
         gbeta = None if sums is None else sum_g
         gres = gout if has_res else None
-        return gx, gW, gb, ggamma, gbeta, None, None, gres, None, None, None, None
+        return gx, gW, gb, ggamma, gbeta, None, None, None, gres, None, None, None, None
 
 
 def linear_bn_act(x, weight, bias, bn, slope, residual=None):
@@ -599,10 +603,9 @@ def linear_bn_act(x, weight, bias, bn, slope, residual=None):
     training = bn.training or bn.running_mean is None
     if training and x2.shape[0] <= 1:
         raise ValueError("Expected more than 1 value per channel when training (BatchNorm1d)")
-    if training and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
     momentum = 0.1 if bn.momentum is None else bn.momentum
     res2 = None if residual is None else _f32(residual).reshape(-1, weight.shape[0])
-    out = _LinearBNAct.apply(x2, _f32(weight), bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, res2,
-                             training, momentum, bn.eps, 1.0 if slope is None else slope)
+    out = _LinearBNAct.apply(x2, _f32(weight), bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                             bn.num_batches_tracked if training else None, res2, training, momentum, bn.eps,
+                             1.0 if slope is None else slope)
     return out.view(*lead, weight.shape[0])

@@ -197,7 +197,11 @@ def test_gemm_vs_torch(ops, M, N, K, tA, tB):
     C = torch.empty(M, N, device="cuda")
     tiles = (M + 63) // 64
     st3 = torch.full((tiles, 2, N), float("nan"), device="cuda")
-    ops._gemm(A, A.shape[1], tA, Bm, Bm.shape[1], tB, bias, C, N, M, N, K, 0, st3)
+    acs = torch.zeros(M, device="cuda") if tA else None
+    ops._gemm(A, A.shape[1], tA, Bm, Bm.shape[1], tB, bias, C, N, M, N, K, 0, st3, a_col_sum=acs)
+    if tA:
+        want = A.double().sum(0)
+        assert float((acs.double() - want).abs().max()) < 1e-5 * float(A.double().abs().sum(0).max())
     ref = (A.double().t() if tA else A.double()) @ (Bm.double().t() if tB else Bm.double()) + bias.double()
     scale = float(ref.abs().max())
     assert float((C.double() - ref).abs().max()) < 2e-6 * scale * max(1.0, K ** 0.5 / 8)
