@@ -150,6 +150,52 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const float *__restrict__ A
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    if constexpr (TA && !TB) {
+        // ---- k-major x k-major (weight gradients: dY^T [K][M] times X [K][N], K = B*S rows):
+        // both MFMA operands are already laid out the way the instruction wants them -- for a
+        // fixed k the 32 lanes of a half-wave read 32 consecutive floats (one 128-B line) -- so
+        // each wave streams its quarter of the K range straight from global memory into
+        // registers, 8 k-pairs (32 loads of 256 B) in flight ahead of the MFMAs.  No LDS staging,
+        // no workgroup barrier in the loop: this product is a pure HBM stream with a tiny output.
+        const int kspan = kend - kbeg;
+        int kq = ((kspan + 3) / 4 + 1) & ~1;                 // per-wave share, even
+        const int k0w = kbeg + wave * kq;
+        const int k1w = min(kend, k0w + kq);
+        const int ma0 = min(m0 + l31, M - 1), ma1 = min(m0 + 32 + l31, M - 1);     // clamped: rows/cols
+        const int nb0 = min(n0 + l31, N - 1), nb1 = min(n0 + 32 + l31, N - 1);     // beyond M,N are dropped
+        constexpr int U = 8;
+        float pa0[U], pa1[U], pb0[U], pb1[U];
+        auto issue = [&](int kb) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int k = kb + 2 * u + half;
+                const bool ok = k < k1w;
+                const float *ar = A + (size_t)(ok ? k : k0w) * lda;
+                const float *br = B + (size_t)(ok ? k : k0w) * ldb;
+                const float x0 = ar[ma0], x1 = ar[ma1], y0 = br[nb0], y1 = br[nb1];
+                pa0[u] = ok ? x0 : 0.f; pa1[u] = ok ? x1 : 0.f;
+                pb0[u] = ok ? y0 : 0.f; pb1[u] = ok ? y1 : 0.f;
+            }
+        };
+        if (k0w < k1w) {
+            issue(k0w);
+            for (int kb = k0w; kb < k1w; kb += 2 * U) {
+                float ca0[U], ca1[U], cb0[U], cb1[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) { ca0[u] = pa0[u]; ca1[u] = pa1[u]; cb0[u] = pb0[u]; cb1[u] = pb1[u]; }
+                if (kb + 2 * U < k1w) issue(kb + 2 * U);
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca0[u], cb0[u], acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca0[u], cb1[u], acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca1[u], cb0[u], acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca1[u], cb1[u], acc[1][1], 0, 0, 0);
+                    asum0 += ca0[u];
+                    asum1 += ca1[u];
+                }
+            }
+        }
+    } else {
     if (nslab > 0) {
         load_slab(0);
         store_slab(lds);
@@ -176,6 +222,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const float *__restrict__ A
         if (s + 1 < nslab) store_slab(lds + ((s + 1) & 1) * BUF);
         __syncthreads();
     }
+
+    }   // LDS-staged main loop
 
     // ---- optional: column sums of op(A) over this workgroup's K range, i.e. sum_k A^T[k][m] -- the
     // bias gradient when A = dY^T in the weight-gradient product.  Only the n-tile 0 workgroups

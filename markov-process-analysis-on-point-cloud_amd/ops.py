@@ -49,7 +49,7 @@ def kernel_timing_results():
     return out
 
 
-def _launch(name, *args, algo_bytes=0, algo_flops=0):
+def _launch(name, *args, algo_bytes=0, algo_flops=0, tag=None):
     fn = getattr(lib, name)
     recs = _TIMERS.get(name) if _TIMERS is not None else None
     if recs is None:
@@ -60,6 +60,11 @@ def _launch(name, *args, algo_bytes=0, algo_flops=0):
     check(fn(*args), name)
     e1.record()
     recs.append((e0, e1, algo_bytes, algo_flops))
+    if _TAGS is not None:
+        _TAGS.append((name, tag, e0, e1))
+
+
+_TAGS = None      # development: per-launch (name, tag, events) when set to a list
 
 
 # FPS start indices: None = draw from the CPU generator per call (reference behaviour); a hook
@@ -373,7 +378,7 @@ def _gemm(A, lda, tA, Bm, ldb, tB, bias, C, ldc, M, N, K, accumulate=0, tile_sta
             ws_bytes = ws.numel() * 4
     _launch("mpa_gemm_f32", _p(A), lda, tA, _p(Bm), ldb, tB, _p(bias), _p(C), ldc, M, N, K, accumulate,
             _p(tile_stats), _p(a_col_sum), _p(ws), ws_bytes, _stream(), algo_bytes=4 * (M * K + N * K + M * N),
-            algo_flops=2 * M * N * K)
+            algo_flops=2 * M * N * K, tag=(M, N, K, tA, tB, tile_stats is not None))
 
 
 _ZEROS = {}
