@@ -100,8 +100,10 @@ class LocalMerge(nn.Module):
         self.feature_Trans = LocalTrans(in_channels, out_channels, knn, usetanh=usetanh, residual=residual)
         self.feature_Trans2 = LocalTrans(in_channels, out_channels, knn, usetanh=usetanh, residual=residual)
 
-    def forward(self, xyz, base_xyz, normal=None, feature=None, FPS_idx=None, xyz_flag=True):
-        dist, idx = knn_point(self.knn, base_xyz, xyz)
+    def forward(self, xyz, base_xyz, normal=None, feature=None, FPS_idx=None, xyz_flag=True, geometry=None):
+        # `geometry` (optional, not in the reference signature): this level's precomputed
+        # (dist, idx) of knn_point(self.knn, base_xyz, xyz) from ops.geometry_pass
+        dist, idx = knn_point(self.knn, base_xyz, xyz) if geometry is None else (geometry.dist, geometry.idx)
         if feature is None:
             merge_features = self.xyz_Trans(features=xyz, idx=idx, pos=base_xyz, FPS_idx=FPS_idx, xyz=True)
         else:
@@ -142,12 +144,17 @@ class KeepHighResolutionModule(nn.Module):
     def forward(self, xyz, normal):
         xyz = xyz.permute(0, 2, 1).contiguous()
         normal = normal.permute(0, 2, 1).contiguous()
-        feat, normal, _, _ = self.la0(xyz=xyz, base_xyz=xyz, normal=normal, xyz_flag=True)
+        # Geometry pass: every FPS level and every xyz-space kNN depends on the input coordinates
+        # only (992 serial FPS iterations on 64 of the 256 CUs), so it runs ahead on a side stream
+        # while la0/la1 keep the rest of the chip busy; each level waits for its own event.
+        geo = ops.geometry_pass(xyz, self.LEVELS, self.la0.knn)
+        feat, normal, _, _ = self.la0(xyz=xyz, base_xyz=xyz, normal=normal, xyz_flag=True, geometry=geo.level(0))
         base = xyz
-        for npoint, la in zip(self.LEVELS, (self.la1, self.la2, self.la3, self.la4, self.la5)):
-            fps_idx, sub = farthest_point_sample(base, npoint, return_xyz=True)
-            feat, normal, _, _ = la(xyz=sub, base_xyz=base, normal=normal, feature=feat, FPS_idx=fps_idx)
-            base = sub
+        for lvl, la in enumerate((self.la1, self.la2, self.la3, self.la4, self.la5), start=1):
+            g = geo.level(lvl)
+            feat, normal, _, _ = la(xyz=g.xyz, base_xyz=base, normal=normal, feature=feat, FPS_idx=g.fps_idx,
+                                    geometry=g)
+            base = g.xyz
         final = self.conv4(self.conv3(feat))                       # [B,32,1024]
         fused = torch.cat((final.max(dim=1)[0], final.mean(dim=1)), 1)
         return ops.linear_bn_act(fused, self.final_class.weight, self.final_class.bias, self.bn, 0.2)

@@ -176,6 +176,75 @@ def three_nn(xyz1, xyz2):
     return knn_point(3, xyz2, xyz1)
 
 
+# ------------------------------------------------------------------------------- geometry pass
+class _GeoLevel:
+    __slots__ = ("xyz", "fps_idx", "dist", "idx", "event")
+
+
+class GeometryPass:
+    """All sampling levels and xyz-space neighbourhoods of one forward, produced on a side stream.
+    level(i) makes the current stream wait for level i's event and returns its tensors."""
+
+    def __init__(self, levels, side):
+        self.levels, self.side = levels, side
+
+    def level(self, i):
+        g = self.levels[i]
+        if g.event is not None:
+            torch.cuda.current_stream().wait_event(g.event)
+            g.event = None
+        return g
+
+
+_GEO_STREAMS = {}
+GEOMETRY_SIDE_STREAM = False     # True: side stream (measured: no gain under HIP-graph replay on MI355X, r01)
+
+
+def geometry_pass(xyz, npoints, k):
+    """FPS chain xyz -> npoints[0] -> npoints[1] ... and, per level, knn_point(k, base, sampled)
+    (level 0: knn_point(k, xyz, xyz)).  Depends on the coordinates only, so it is
+    issued on a side stream and overlaps the feature path; FPS start indices are drawn (or fed)
+    in the reference's order."""
+    _dev(xyz)
+    cur = torch.cuda.current_stream(xyz.device)
+    use_side = GEOMETRY_SIDE_STREAM
+    side = None
+    if use_side:
+        side = _GEO_STREAMS.get(xyz.device.index)
+        if side is None:
+            side = _GEO_STREAMS[xyz.device.index] = torch.cuda.Stream(xyz.device)
+        side.wait_stream(cur)
+    levels = []
+    ctx = torch.cuda.stream(side) if use_side else _NullCtx()
+    with ctx, torch.no_grad():
+        base = xyz
+        for i in range(len(npoints) + 1):
+            g = _GeoLevel()
+            if i == 0:
+                g.xyz, g.fps_idx = xyz, None
+            else:
+                g.fps_idx, g.xyz = farthest_point_sample(base, npoints[i - 1], return_xyz=True)
+            g.dist, g.idx = knn_point(k, base, g.xyz)
+            g.event = None
+            if use_side:
+                g.event = torch.cuda.Event()
+                g.event.record(side)
+                for t in (g.xyz, g.fps_idx, g.dist, g.idx):
+                    if t is not None and t is not xyz:
+                        t.record_stream(cur)
+            levels.append(g)
+            base = g.xyz
+    return GeometryPass(levels, side)
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
 # ------------------------------------------------------------------------------- gathers
 class _IndexPoints(torch.autograd.Function):
     @staticmethod

@@ -176,11 +176,16 @@ class _ForcedKnn:
     indices; the count of calls where the GPU's own choice differed is reported."""
 
     def __init__(self, real, recorded):
-        self.real, self.recorded, self.i, self.flips, self.total = real, recorded, 0, 0, 0
+        self.real, self.recorded, self.i, self.flips, self.total = real, list(recorded), 0, 0, 0
+        self.used = [False] * len(self.recorded)
 
     def __call__(self, nsample, xyz, new_xyz):
         dist, idx = self.real(nsample, xyz, new_xyz)
-        ref = self.recorded[self.i].to(idx.device)
+        # the reference's recorded call with this shape that has not been used yet (the geometry
+        # pass issues all xyz-space kNNs first; per shape the reference's order is xyz, feature)
+        j = next(j for j, r in enumerate(self.recorded) if not self.used[j] and tuple(r.shape) == tuple(idx.shape))
+        self.used[j] = True
+        ref = self.recorded[j].to(idx.device)
         self.i += 1
         self.flips += int((idx != ref).any(-1).sum())
         self.total += idx.shape[0] * idx.shape[1]
@@ -189,7 +194,9 @@ class _ForcedKnn:
 
 def _run_model(g, model, run, patch_mods, prefix):
     rec = [GL(g["%sknn%d" % (prefix, i)]) for i in range(sum(1 for k in g if k.startswith(prefix + "knn")))]
-    forced = _ForcedKnn(patch_mods[0].knn_point, rec)
+    import mpa_amd.ops as _ops
+    patch_mods = list(patch_mods) + [_ops]          # geometry_pass calls ops.knn_point directly
+    forced = _ForcedKnn(_ops.knn_point, rec)
     saved = [m.knn_point for m in patch_mods]
     for m in patch_mods:
         m.knn_point = forced
