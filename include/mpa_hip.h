@@ -128,6 +128,21 @@ int mpa_diffattn_xyz_bwd_f32(const float *xyz, const float *center, const int64_
 int mpa_gemm_f32(const float *A, int lda, int transA, const float *B, int ldb, int transB,
                  const float *bias, float *C, int ldc, int M, int N, int K, int accumulate,
                  float *tile_stats, float *a_col_sum, float *workspace, size_t workspace_bytes, void *stream);
+/* Grouped weight gradients: out_p[M,N] = A_p^T B_p for `count` independent problems in one launch
+ * (+ one reduce launch), A_p stored [K][M] (lda), B_p stored [K][N] (ldb): dW = dY^T X of every
+ * Linear of a backward pass.  Each is a latency-bound stream with a tiny output, so they are
+ * overlapped instead of launched one by one.  a_col_sum (optional, [M], cleared by the caller)
+ * receives the column sums of A (the bias gradient).  `problems` is a HOST array (copied into
+ * the kernel arguments); workspace holds the split-K partial tiles. */
+typedef struct MpaGemmTnProblem {
+    const float *A;
+    const float *B;
+    float *out;
+    float *a_col_sum;
+    int lda, ldb, M, N, K;
+} MpaGemmTnProblem;
+int mpa_gemm_tn_grouped_f32(const MpaGemmTnProblem *problems, int count, float *workspace,
+                            size_t workspace_bytes, void *stream);
 /* tile statistics (same format as the GEMM epilogue's) of an existing tensor x [M,C]. */
 int mpa_tile_stats_f32(const float *x, int M, int C, float *tile_stats, void *stream);
 /* per-column sum and sum of squares of x [M,C] -> col_sum, col_sumsq [C] (caller zeroes). */

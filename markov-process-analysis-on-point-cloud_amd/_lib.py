@@ -52,6 +52,14 @@ SIGNATURES = {
     "mpa_three_interp_bwd_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
 }
 
+class GemmTnProblem(ctypes.Structure):
+    """struct MpaGemmTnProblem of include/mpa_hip.h"""
+    _fields_ = [("A", _vp), ("B", _vp), ("out", _vp), ("a_col_sum", _vp),
+                ("lda", _i), ("ldb", _i), ("M", _i), ("N", _i), ("K", _i)]
+
+
+SIGNATURES["mpa_gemm_tn_grouped_f32"] = [ctypes.POINTER(GemmTnProblem), _i, _vp, ctypes.c_size_t, _vp]
+
 for _name, _args in SIGNATURES.items():
     _fn = getattr(lib, _name)
     _fn.argtypes = _args

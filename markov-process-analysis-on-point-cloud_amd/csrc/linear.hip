@@ -33,12 +33,11 @@ constexpr int KS = 64;    // K slab staged per iteration; each of the 4 waves ow
 // LDS, which also turns the epilogue into coalesced float4 row stores with the bias, the
 // BatchNorm column statistics and (for split-K across workgroups) float atomics.
 template <bool TA, bool TB>
-__global__ __launch_bounds__(NT, 2) void gemm_kernel(const float *__restrict__ A, int lda,
-                                                     const float *__restrict__ B, int ldb,
-                                                     const float *__restrict__ bias, float *__restrict__ C, int ldc,
-                                                     int M, int N, int K, int kchunk, int out_mode, int vecA,
-                                                     int vecB, float *__restrict__ tile_stats, float *__restrict__ zero_c,
-                                                     float *__restrict__ a_col_sum)
+__device__ __forceinline__ void gemm_body(const int block_x, const int block_z, const float *__restrict__ A, int lda,
+                                          const float *__restrict__ B, int ldb, const float *__restrict__ bias,
+                                          float *__restrict__ C, int ldc, int M, int N, int K, int kchunk,
+                                          int out_mode, int vecA, int vecB, float *__restrict__ tile_stats,
+                                          float *__restrict__ zero_c, float *__restrict__ a_col_sum)
 {
     // out_mode 0: C = result (+bias);  1: atomicAdd into C;  2: split-K partial slab
     //             C + blockIdx.z*M*ldc (plain stores, summed by splitk_reduce_kernel).
@@ -64,10 +63,10 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const float *__restrict__ A
     // each XCD a contiguous run of tiles (tiles sharing A rows / B columns then share an L2).
     const int tiles_n = (N + TS - 1) / TS, tiles_m = (M + TS - 1) / TS;
     const int ntiles = tiles_m * tiles_n;
-    int id = blockIdx.x;
+    int id = block_x;
     if ((ntiles & 7) == 0) id = (id & 7) * (ntiles >> 3) + (id >> 3);
     const int m0 = (id / tiles_n) * TS, n0 = (id % tiles_n) * TS;
-    const int kbeg = blockIdx.z * kchunk;
+    const int kbeg = block_z * kchunk;
     const int kend = min(K, kbeg + kchunk);
     const int nslab = (kend - kbeg + KS - 1) / KS;
 
@@ -253,7 +252,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const float *__restrict__ A
     if (out_mode == 1) {
         // float atomics want 256 contiguous bytes per wave instruction: lane = column
         const int cl = tid & 63, colA = n0 + cl;
-        const float bA = (bias != nullptr && blockIdx.z == 0 && colA < N) ? bias[colA] : 0.f;
+        const float bA = (bias != nullptr && block_z == 0 && colA < N) ? bias[colA] : 0.f;
 #pragma unroll 4
         for (int q = 0; q < 16; ++q) {
             const int rloc = (tid >> 6) + 4 * q;
@@ -266,7 +265,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const float *__restrict__ A
     if (out_mode == 2) {
         // split-K slabs are summed into the real output by splitk_reduce_kernel (atomics): the z = 0
         // workgroups clear their tile of it here, saving a separate memset launch
-        if (zero_c != nullptr && blockIdx.z == 0) {
+        if (zero_c != nullptr && block_z == 0) {
             const int cz = n0 + (tid & 15) * 4;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -276,13 +275,13 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const float *__restrict__ A
                         if (cz + e < N) zero_c[(size_t)rz * ldc + cz + e] = 0.f;
             }
         }
-        C += (size_t)blockIdx.z * M * ldc;
+        C += (size_t)block_z * M * ldc;
     }
 
     const int c4 = (tid & 15) * 4;            // this lane's 4 columns (same for its 4 rows)
     const int col = n0 + c4;
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (bias != nullptr && blockIdx.z == 0) {
+    if (bias != nullptr && block_z == 0) {
         if (col < N) bv.x = bias[col];
         if (col + 1 < N) bv.y = bias[col + 1];
         if (col + 2 < N) bv.z = bias[col + 2];
@@ -369,6 +368,85 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const float *__restrict__ A
             dst[N] = m2;
         }
     }
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(NT, 2) void gemm_kernel(const float *__restrict__ A, int lda,
+                                                     const float *__restrict__ B, int ldb,
+                                                     const float *__restrict__ bias, float *__restrict__ C, int ldc,
+                                                     int M, int N, int K, int kchunk, int out_mode, int vecA,
+                                                     int vecB, float *__restrict__ tile_stats, float *__restrict__ zero_c,
+                                                     float *__restrict__ a_col_sum)
+{
+    gemm_body<TA, TB>(blockIdx.x, blockIdx.z, A, lda, B, ldb, bias, C, ldc, M, N, K, kchunk, out_mode, vecA, vecB,
+                      tile_stats, zero_c, a_col_sum);
+}
+
+// ---- grouped weight-gradient products: many independent small  out_p[M_p,N_p] = A_p^T B_p  (A_p, B_p
+// k-major with K_p = B*S rows) in ONE launch.  Each is a latency-bound HBM stream with a tiny
+// output; issued one by one they cost ~17 us apiece with most of the chip idle, together their
+// streams overlap.  Problem descriptors travel in the kernel arguments (no device table).
+struct GroupedProblem {
+    const float *A, *B;
+    float *out, *a_col_sum, *slab;       // slab: split-K partial tiles [splits][M*N] (or nullptr: direct)
+    int lda, ldb, M, N, K, kchunk, splits, tiles;
+};
+constexpr int GROUP_MAX = 40;
+struct GroupedArgs {
+    int count;
+    int block_start[GROUP_MAX + 1];      // prefix sum of tiles*splits
+    GroupedProblem p[GROUP_MAX];
+};
+
+__global__ __launch_bounds__(NT, 2) void gemm_tn_grouped_kernel(const GroupedArgs args)
+{
+    __shared__ int which;
+    if (threadIdx.x == 0) {
+        int b = blockIdx.x, i = 0;
+        while (i + 1 < args.count && b >= args.block_start[i + 1]) ++i;
+        which = i;
+    }
+    __syncthreads();
+    const GroupedProblem &q = args.p[which];
+    const int local = blockIdx.x - args.block_start[which];
+    const int tile = local % q.tiles, z = local / q.tiles;
+    const int vecA = 0, vecB = 0;        // unused by the streaming path
+    if (q.slab != nullptr)
+        gemm_body<true, false>(tile, z, q.A, q.lda, q.B, q.ldb, nullptr, q.slab, q.N, q.M, q.N, q.K, q.kchunk, 2, vecA,
+                               vecB, nullptr, q.out, q.a_col_sum);
+    else
+        gemm_body<true, false>(tile, z, q.A, q.lda, q.B, q.ldb, nullptr, q.out, q.N, q.M, q.N, q.K, q.kchunk, 0, vecA,
+                               vecB, nullptr, nullptr, q.a_col_sum);
+}
+
+// out_p[M*N] += sum_z slab_p[z][M*N] for all problems of a group (out_p cleared by the z = 0 tiles above)
+struct GroupedReduceArgs {
+    int count;
+    int block_start[GROUP_MAX + 1];      // prefix sum of ceil(mn/256)*gy
+    struct { const float *slab; float *out; int mn, splits, gx, gy; } p[GROUP_MAX];
+};
+
+__global__ void splitk_reduce_grouped_kernel(const GroupedReduceArgs args)
+{
+    int b = blockIdx.x, i = 0;
+    while (i + 1 < args.count && b >= args.block_start[i + 1]) ++i;
+    const auto &q = args.p[i];
+    const int local = b - args.block_start[i];
+    const int bx = local % q.gx, by = local / q.gx;
+    const long long e = bx * 256LL + threadIdx.x;
+    if (e >= q.mn) return;
+    const int zper = (q.splits + q.gy - 1) / q.gy;
+    const int z0 = by * zper, z1 = min(q.splits, z0 + zper);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int z = z0;
+    for (; z + 3 < z1; z += 4) {
+        a0 += q.slab[(size_t)z * q.mn + e];
+        a1 += q.slab[(size_t)(z + 1) * q.mn + e];
+        a2 += q.slab[(size_t)(z + 2) * q.mn + e];
+        a3 += q.slab[(size_t)(z + 3) * q.mn + e];
+    }
+    for (; z < z1; ++z) a0 += q.slab[(size_t)z * q.mn + e];
+    if (z0 < z1) atomicAdd(q.out + e, (a0 + a1) + (a2 + a3));
 }
 
 constexpr size_t gemm_lds_bytes(bool, bool) { return sizeof(float) * 2 * KS * (TS + TS); }   // 64 KiB
@@ -792,6 +870,67 @@ extern "C" int mpa_gemm_f32(const float *A, int lda, int transA, const float *B,
         if (accumulate) return MPA_EUNSUPPORTED;
         hipLaunchKernelGGL(tile_stats_kernel, dim3(mpa_ceil_div(N, 64), mpa_ceil_div(M, TS)), dim3(256), 0, st, C, M, N,
                            tile_stats);
+    }
+    MPA_LAUNCH_CHECK();
+    return MPA_OK;
+}
+
+extern "C" int mpa_gemm_tn_grouped_f32(const MpaGemmTnProblem *problems, int count, float *workspace,
+                                       size_t workspace_bytes, void *stream)
+{
+    MPA_CLEAR_ERROR();
+    if (!problems || count <= 0) return MPA_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    size_t ws_used = 0;
+    int done = 0;
+    while (done < count) {
+        GroupedArgs ga;
+        GroupedReduceArgs ra;
+        int n = 0, nr = 0, blocks = 0, rblocks = 0;
+        ga.block_start[0] = 0;
+        ra.block_start[0] = 0;
+        for (; done < count && n < GROUP_MAX; ++done) {
+            const MpaGemmTnProblem &in = problems[done];
+            if (!in.A || !in.B || !in.out || in.M <= 0 || in.N <= 0 || in.K <= 0 || in.lda < in.M || in.ldb < in.N)
+                return MPA_EINVAL;
+            GroupedProblem &q = ga.p[n];
+            q.A = in.A; q.B = in.B; q.out = in.out; q.a_col_sum = in.a_col_sum;
+            q.lda = in.lda; q.ldb = in.ldb; q.M = in.M; q.N = in.N; q.K = in.K;
+            q.tiles = mpa_ceil_div(in.M, TS) * mpa_ceil_div(in.N, TS);
+            const size_t mn = (size_t)in.M * in.N;
+            int splits = 1;
+            if (q.tiles < 256 && in.K >= 512) {
+                splits = (512 + q.tiles - 1) / q.tiles;
+                if (splits > in.K / 256) splits = in.K / 256;
+                const size_t room = workspace ? (workspace_bytes - ws_used) / (mn * sizeof(float)) : 0;
+                if ((size_t)splits > room) splits = (int)room;
+                if (splits < 1) splits = 1;
+            }
+            q.kchunk = mpa_ceil_div(mpa_ceil_div(in.K, splits), KS) * KS;
+            q.splits = mpa_ceil_div(in.K, q.kchunk);
+            q.slab = nullptr;
+            if (q.splits > 1) {
+                q.slab = workspace + ws_used / sizeof(float);
+                ws_used += (size_t)q.splits * mn * sizeof(float);
+                ws_used = (ws_used + 255) & ~(size_t)255;
+                auto &r = ra.p[nr];
+                r.slab = q.slab; r.out = q.out; r.mn = (int)mn; r.splits = q.splits;
+                r.gx = mpa_ceil_div((long long)mn, 256);
+                int gy = mpa_ceil_div(1024, r.gx);
+                gy = gy > 32 ? 32 : gy;
+                r.gy = gy > q.splits ? q.splits : gy;
+                rblocks += r.gx * r.gy;
+                ra.block_start[++nr] = rblocks;
+            } else {
+                q.kchunk = mpa_ceil_div(in.K, KS) * KS;
+            }
+            blocks += q.tiles * q.splits;
+            ga.block_start[++n] = blocks;
+        }
+        ga.count = n;
+        ra.count = nr;
+        hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(blocks), dim3(NT), gemm_lds_bytes(true, false), st, ga);
+        if (nr > 0) hipLaunchKernelGGL(splitk_reduce_grouped_kernel, dim3(rblocks), dim3(256), 0, st, ra);
     }
     MPA_LAUNCH_CHECK();
     return MPA_OK;

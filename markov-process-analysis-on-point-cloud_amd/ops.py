@@ -11,7 +11,7 @@ import ctypes
 
 import torch
 
-from ._lib import lib, check
+from ._lib import lib, check, GemmTnProblem
 
 _vp = ctypes.c_void_p
 
@@ -463,6 +463,54 @@ def _zeros_like_cached(device, n):
     return z
 
 
+# ---- deferred, grouped weight gradients ---------------------------------------------------------
+# Nothing in a backward pass consumes a weight gradient, so when the gradients are written straight
+# into flat buckets (GradReducer direct mode) the dW = dY^T X products can be queued and issued
+# together at the end of backward (flush_weight_grads): ~60 latency-bound launches become two.
+_DW_QUEUE = None          # None: immediate mode; list: deferral active
+
+
+def defer_weight_grads(on=True):
+    """Enable / disable queuing of direct-mode weight-gradient GEMMs (flush_weight_grads() required
+    after every backward while enabled)."""
+    global _DW_QUEUE
+    if on and _DW_QUEUE is None:
+        _DW_QUEUE = []
+    elif not on:
+        if _DW_QUEUE:
+            flush_weight_grads()
+        _DW_QUEUE = None
+
+
+def _weight_grad(gy, lda, x, ldb, out, M, N, K, a_col_sum=None, direct=False):
+    """out[M,N] = gy^T x  (gy stored [K][M] with row stride lda, x stored [K][N] with ldb)."""
+    if direct and _DW_QUEUE is not None:
+        _DW_QUEUE.append((gy, lda, x, ldb, out, M, N, K, a_col_sum))
+    else:
+        _gemm(gy, lda, 1, x, ldb, 0, None, out, N, M, N, K, a_col_sum=a_col_sum)
+
+
+def flush_weight_grads():
+    """Issue every queued weight-gradient product as one grouped launch (+ one reduce)."""
+    if not _DW_QUEUE:
+        return
+    n = len(_DW_QUEUE)
+    arr = (GemmTnProblem * n)()
+    ws_bytes = 0
+    for i, (gy, lda, x, ldb, out, M, N, K, acs) in enumerate(_DW_QUEUE):
+        arr[i].A, arr[i].B, arr[i].out = gy.data_ptr(), x.data_ptr(), out.data_ptr()
+        arr[i].a_col_sum = acs.data_ptr() if acs is not None else None
+        arr[i].lda, arr[i].ldb, arr[i].M, arr[i].N, arr[i].K = lda, ldb, M, N, K
+        tiles = ((M + 63) // 64) * ((N + 63) // 64)
+        if tiles < 256 and K >= 512:
+            splits = max(1, min((512 + tiles - 1) // tiles, K // 256))
+            ws_bytes += (splits * M * N * 4 + 255) // 256 * 256
+    dev = _DW_QUEUE[0][0].device
+    ws = _workspace(dev, max(ws_bytes, 4))
+    _launch("mpa_gemm_tn_grouped_f32", arr, n, _p(ws), ws.numel() * 4, _stream())
+    _DW_QUEUE.clear()
+
+
 def _col_sum(x2d, ld=None):
     M, C = x2d.shape
     out = torch.zeros(C, dtype=torch.float32, device=x2d.device)
@@ -518,7 +566,7 @@ class _Linear(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             gW = dW if dW is not None else torch.empty(N, K, dtype=torch.float32, device=x.device)
             # gy^T [N,M] @ x [M,K]; the bias gradient (column sums of gy) rides along
-            _gemm(gy, N, 1, x, K, 0, None, gW, K, N, K, M, a_col_sum=gb_buf)
+            _weight_grad(gy, N, x, K, gW, N, K, M, a_col_sum=gb_buf, direct=dW is not None and (gb_buf is None or db is not None))
             if dW is not None:
                 gW = None
         elif want_b:
@@ -572,10 +620,10 @@ class _LinearKV(torch.autograd.Function):
         gv_view = gkv[:, C:]
         gWk = dWk if dWk is not None else torch.empty(C, K, dtype=torch.float32, device=dev)
         gWv = dWv if dWv is not None else torch.empty(C, K, dtype=torch.float32, device=dev)
-        _gemm(gkv, 2 * C, 1, x, K, 0, None, gWk, K, C, K, M)                     # gk^T x
+        _weight_grad(gkv, 2 * C, x, K, gWk, C, K, M, direct=dWk is not None)                     # gk^T x
         # gv^T x; its A operand's column sums are dbv (accumulated by the same kernel)
         gbv = dbv if dbv is not None else torch.zeros(C, dtype=torch.float32, device=dev)
-        _gemm(gv_view, 2 * C, 1, x, K, 0, None, gWv, K, C, K, M, a_col_sum=gbv)
+        _weight_grad(gv_view, 2 * C, x, K, gWv, C, K, M, a_col_sum=gbv, direct=dWv is not None and dbv is not None)
         if dbv is not None:
             gbv = None
         gbk = None if dbk is not None else _zeros_like_cached(dev, C)
@@ -647,7 +695,7 @@ class _LinearBNAct(torch.autograd.Function):
             _gemm(gy, N, 0, W, K, 0, None, gx, K, M, K, N)
         if ctx.needs_input_grad[1]:
             gW = dW if dW is not None else torch.empty(N, K, dtype=torch.float32, device=dev)
-            _gemm(gy, N, 1, x, K, 0, None, gW, K, N, K, M)
+            _weight_grad(gy, N, x, K, gW, N, K, M, direct=dW is not None)
             if dW is not None:
                 gW = None
         if has_bias and ctx.needs_input_grad[2]:

@@ -98,7 +98,12 @@ class GraphedTrainStep:
         self.feeder.begin_pass()
         self.reducer.zero_grad()
         loss = self.loss_fn(self.model(self.static[0]), *self.static[1:])
-        loss.backward()
+        ops.defer_weight_grads(True)          # dW products are queued during backward ...
+        try:
+            loss.backward()
+            ops.flush_weight_grads()          # ... and issued as one grouped launch
+        finally:
+            ops.defer_weight_grads(False)
         return loss
 
     def __call__(self, *batch):

@@ -308,10 +308,21 @@ def test_direct_grad_mode_matches_autograd(P, RS, golden_cls):
     red = GradReducer(model, direct=True)
     red.overlap = False
     red.all_reduce()                       # builds the flat buckets from the existing gradients
-    for _ in range(2):
+    import mpa_amd.ops as _ops
+    for deferred in (False, True):          # immediate and queued/grouped weight gradients
         red.zero_grad()
-        run()
+        _ops.defer_weight_grads(deferred)
+        try:
+            run()
+            _ops.flush_weight_grads()
+        finally:
+            _ops.defer_weight_grads(False)
         red.all_reduce()
+        got = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+        assert set(got) == set(plain)
+        gmax = max(float(v.abs().max()) for v in plain.values())
+        for n in plain:
+            assert float((got[n] - plain[n]).abs().max()) <= 2e-4 * gmax, (n, deferred)
     got = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
     assert set(got) == set(plain)
     gmax = max(float(v.abs().max()) for v in plain.values())
