@@ -178,6 +178,12 @@ def main():
 
     if rank == 0:
         clouds = a.batch * world * a.steps
+        traffic = {}
+        try:        # HBM bytes per launch from the committed rocprofv3 PMC passes (see the file's "how")
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+                traffic = {k: v.get("hbm_bytes_per_launch") for k, v in json.load(fh)["kernels"].items()}
+        except (OSError, ValueError, KeyError):
+            pass
         kernels = []
         for name, bound in TIMED.items():
             r = kt.get(name)
@@ -189,7 +195,7 @@ def main():
             else:
                 ach, peak, unit = r["algo_flops"] / sec / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
             kernels.append({"kernel": name, "bound": bound, "achieved": ach, "peak": peak, "unit": unit,
-                            "frac": ach / peak, "traffic": None, "launches": r["launches"],
+                            "frac": ach / peak, "traffic": traffic.get(name), "launches": r["launches"],
                             "avg_launch_us": r["ms"] * 1e3 / r["launches"], "total_ms": r["ms"],
                             "algo_bytes_per_launch": r["algo_bytes"] / r["launches"],
                             "algo_flops_per_launch": r["algo_flops"] / r["launches"]})

@@ -213,6 +213,25 @@ def gen_fuse():
     save("fuse.npz", d)
 
 
+# ------------------------------------------------------------------ RepSurf-style set abstraction (a14)
+def gen_sa():
+    d = {}
+    B, N = 2, 512
+    xyz = unit_cloud(B, N, seed=950)
+    nrm = randn((B, N, 3), seed=951)
+    feat = randn((B, N, 16), seed=952)
+    torch.manual_seed(21)
+    c, n, f = rs.sample_and_group(128, 0.2, 24, xyz, nrm, feat, return_normal=True, return_polar=False, cuda=False)
+    d["xyz"], d["normal"], d["feature"] = npy(xyz), npy(nrm), npy(feat)
+    d["sg/center"], d["sg/normal"], d["sg/feature"] = npy(c), npy(n), npy(f)
+    m = fill_state(rs.SurfaceAbstractionCD(npoint=128, radius=0.2, nsample=24, feat_channel=16 + 3, pos_channel=3,
+                                           mlp=[32, 64], group_all=False, return_polar=False, cuda=False), seed=7).train()
+    torch.manual_seed(21)
+    oc, on, of = m(xyz.transpose(1, 2), nrm.transpose(1, 2), feat.transpose(1, 2))
+    d["sa/center"], d["sa/normal"], d["sa/feature"] = npy(oc), npy(on), npy(of)
+    save("sa.npz", d)
+
+
 # ------------------------------------------------------------------ whole models
 def model_golden(model, run, params_full):
     """run(model) -> output tensor.  Returns eval output, train output, loss grads."""
@@ -323,7 +342,9 @@ def gen_seg():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["index", "blocks", "fuse", "cls", "seg"]
+    which = sys.argv[1:] or ["index", "blocks", "fuse", "sa", "cls", "seg"]
+    if "sa" in which:
+        gen_sa()
     if "index" in which:
         gen_index_ops()
     if "blocks" in which:

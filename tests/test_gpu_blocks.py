@@ -357,3 +357,33 @@ def test_flat_adam_matches_torch_adam():
         mine.step()
     for pa, pb in zip(a.parameters(), b.parameters()):
         assert torch.allclose(pa, pb, atol=2e-6, rtol=1e-5)
+
+
+def test_sample_and_group_and_surface_abstraction(RS):
+    """a14: FPS + ball query + grouping (RepSurf baseline set abstraction) against the reference."""
+    from conftest import load_golden
+    g = load_golden("sa.npz")
+    xyz, nrm, feat = G(g["xyz"]), G(g["normal"]), G(g["feature"])
+    torch.manual_seed(21)
+    c, n, f = RS.sample_and_group(128, 0.2, 24, xyz, nrm, feat, return_normal=True, return_polar=False)
+    assert np.array_equal(c.cpu().numpy(), g["sg/center"])          # gathers of exact indices: bitwise
+    assert np.array_equal(n.cpu().numpy(), g["sg/normal"])
+    assert np.array_equal(f.cpu().numpy(), g["sg/feature"])
+    m = fill_state(RS.SurfaceAbstractionCD(npoint=128, radius=0.2, nsample=24, feat_channel=16 + 3, pos_channel=3,
+                                           mlp=[32, 64], group_all=False, return_polar=False), seed=7).cuda().train()
+    torch.manual_seed(21)
+    oc, on, of = m(xyz.transpose(1, 2), nrm.transpose(1, 2), feat.transpose(1, 2))
+    assert np.array_equal(oc.cpu().numpy(), g["sa/center"])
+    close(of, g["sa/feature"], what="SurfaceAbstractionCD features")
+
+
+def test_sample_legacy_helper(P):
+    """`sample(nsample, feature[B,C,N])`: FPS-downsample of a channel-first batch (tool/train_cls_scanobjectnn.py:244)."""
+    from param_fill import unit_cloud
+    pts = torch.cat([unit_cloud(3, 300, seed=5), randn((3, 300, 3), seed=6)], dim=2).transpose(1, 2).contiguous().cuda()
+    torch.manual_seed(9)
+    out = P.sample(100, pts)
+    torch.manual_seed(9)
+    idx = P.farthest_point_sample(pts[:, :3].transpose(1, 2).contiguous(), 100)
+    ref = torch.gather(pts, 2, idx.unsqueeze(1).expand(-1, 6, -1))
+    assert out.shape == (3, 6, 100) and torch.equal(out, ref)
