@@ -163,17 +163,19 @@ int mpa_bn_act_fwd_f32(const float *x, const float *save_mean_invstd, const floa
                        const float *residual, float slope, int M, int C, float *y, void *stream);
 /* out[c] += sum over the M rows of x[r*ld + c]  (bias gradients; out [C] cleared by the caller). */
 int mpa_col_sum_f32(const float *x, int M, int C, int ld, float *out, void *stream);
-/* backward of y = lrelu(bn(x)): pass 1 accumulates (caller zeroes) sum_g[c] = sum g and
- * sum_gxhat[c] = sum g*xhat with g = grad_y * lrelu'(.)  (these are dbeta and dgamma);
- * pass 2 writes grad_x = gamma*invstd*(g - sum_g/M - xhat*sum_gxhat/M) (use_batch_stats != 0)
- * or gamma*invstd*g (running statistics). */
+/* backward of y = lrelu(bn(x)).  Pass 1 accumulates, with float atomics spread over `replicas`
+ * copies, partial[r][0][c] += sum g and partial[r][1][c] += sum g*xhat (g = grad_y * lrelu'(.);
+ * partial [replicas][2][C] pre-zeroed, e.g. by mpa_bn_finalize_f32's zero_buf).  Pass 2 sums the
+ * replicas, writes grad_x = gamma*invstd*(g - sum_g/M - xhat*sum_gxhat/M) (use_batch_stats != 0)
+ * or gamma*invstd*g (running statistics), and stores dbeta = sum g, dgamma = sum g*xhat
+ * (either may be NULL). */
 int mpa_bn_act_bwd_reduce_f32(const float *x, const float *grad_y, const float *mean, const float *invstd,
                               const float *gamma, const float *beta, float slope, int M, int C,
-                              float *sum_g, float *sum_gxhat, void *stream);
+                              float *partial, int replicas, void *stream);
 int mpa_bn_act_bwd_apply_f32(const float *x, const float *grad_y, const float *mean, const float *invstd,
-                             const float *gamma, const float *beta, const float *sum_g,
-                             const float *sum_gxhat, float slope, int use_batch_stats, int M, int C,
-                             float *grad_x, void *stream);
+                             const float *gamma, const float *beta, const float *partial, int replicas,
+                             float slope, int use_batch_stats, int M, int C, float *grad_x, float *dgamma,
+                             float *dbeta, void *stream);
 
 /* ---- upsample: the decoder's coarse->fine transition, modules/pointnet2_utils.py:13-50.
  * points [B,S,C], knn_idx [B,S,K] with values < Nf (= S*scale_ratio).  out [B,Nf,C] is the

@@ -728,8 +728,10 @@ __device__ __forceinline__ void slab_reduce2(int M, int C, int cpb, int rows_per
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(
     const float *__restrict__ x, const float *__restrict__ gy, const float *__restrict__ mean,
     const float *__restrict__ invstd, const float *__restrict__ gamma, const float *__restrict__ beta, float slope,
-    int M, int C, int cpb, int rows_per_block, float *__restrict__ sum_g, float *__restrict__ sum_gx)
+    int M, int C, int cpb, int rows_per_block, float *__restrict__ partial, int replicas)
 {
+    float *sum_g = partial + (size_t)(blockIdx.x % replicas) * 2 * C;
+    float *sum_gx = sum_g + C;
     slab_reduce2(M, C, cpb, rows_per_block, sum_g, sum_gx, [&](int r, int c, float &sg, float &sgx) {
         const float xh = (x[(size_t)r * C + c] - mean[c]) * invstd[c];
         const float t = xh * gamma[c] + beta[c];
@@ -740,26 +742,134 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(
     });
 }
 
+// float4 form (C % 4 == 0): a lane owns 4 adjacent channels, 256 lanes = RY rows x C/4 lanes, two
+// rows (4 x 16-B loads) in flight per lane; RY partials combined through LDS, one atomic per
+// (workgroup, channel).
+__global__ __launch_bounds__(256) void bn_act_bwd_reduce4_kernel(
+    const float *__restrict__ x, const float *__restrict__ gy, const float *__restrict__ mean,
+    const float *__restrict__ invstd, const float *__restrict__ gamma, const float *__restrict__ beta, float slope,
+    int M, int C, int lanes_per_row, int rows_per_block, float *__restrict__ partial, int replicas)
+{
+    // partial [replicas][2][C] (pre-zeroed): workgroups spread their atomics over the replicas so
+    // that at most gridDim.x/replicas of them add into one address; the apply pass sums them.
+    float *__restrict__ sum_g = partial + (size_t)(blockIdx.x % replicas) * 2 * C;
+    float *__restrict__ sum_gx = sum_g + C;
+    __shared__ float4 red[2][256];
+    const int tid = threadIdx.x;
+    const int ry = tid / lanes_per_row, cl = tid - ry * lanes_per_row, RY = 256 / lanes_per_row;
+    const int c = (blockIdx.y * lanes_per_row + cl) * 4;
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    float4 sg = make_float4(0.f, 0.f, 0.f, 0.f), sx = sg;
+    if (c < C && ry < RY) {
+        const float4 mu = *reinterpret_cast<const float4 *>(mean + c), is = *reinterpret_cast<const float4 *>(invstd + c);
+        const float4 ga = *reinterpret_cast<const float4 *>(gamma + c), be = *reinterpret_cast<const float4 *>(beta + c);
+        auto acc1 = [&](const float4 xv, const float4 gv) {
+            float xh, t, g;
+            xh = (xv.x - mu.x) * is.x; t = xh * ga.x + be.x; g = t > 0.f ? gv.x : gv.x * slope; sg.x += g; sx.x = fmaf(g, xh, sx.x);
+            xh = (xv.y - mu.y) * is.y; t = xh * ga.y + be.y; g = t > 0.f ? gv.y : gv.y * slope; sg.y += g; sx.y = fmaf(g, xh, sx.y);
+            xh = (xv.z - mu.z) * is.z; t = xh * ga.z + be.z; g = t > 0.f ? gv.z : gv.z * slope; sg.z += g; sx.z = fmaf(g, xh, sx.z);
+            xh = (xv.w - mu.w) * is.w; t = xh * ga.w + be.w; g = t > 0.f ? gv.w : gv.w * slope; sg.w += g; sx.w = fmaf(g, xh, sx.w);
+        };
+        int r = r0 + ry;
+        for (; r + RY < r1; r += 2 * RY) {
+            const float4 x0 = *reinterpret_cast<const float4 *>(x + (size_t)r * C + c);
+            const float4 g0 = *reinterpret_cast<const float4 *>(gy + (size_t)r * C + c);
+            const float4 x1 = *reinterpret_cast<const float4 *>(x + (size_t)(r + RY) * C + c);
+            const float4 g1 = *reinterpret_cast<const float4 *>(gy + (size_t)(r + RY) * C + c);
+            acc1(x0, g0);
+            acc1(x1, g1);
+        }
+        for (; r < r1; r += RY)
+            acc1(*reinterpret_cast<const float4 *>(x + (size_t)r * C + c),
+                 *reinterpret_cast<const float4 *>(gy + (size_t)r * C + c));
+    }
+    red[0][tid] = sg;
+    red[1][tid] = sx;
+    __syncthreads();
+    // consecutive lanes add consecutive channels: float atomics want contiguous 256-B segments
+    const float *rf = reinterpret_cast<const float *>(&red[0][0]);
+    const int cw = lanes_per_row * 4;                    // channels covered by this workgroup
+    for (int t = tid; t < 2 * cw; t += 256) {
+        const int which = t / cw, ch = t - which * cw;
+        const int cg = blockIdx.y * cw + ch;
+        if (cg < C) {
+            float a = 0.f;
+            for (int y = 0; y < RY; ++y) a += rf[(size_t)which * 1024 + (y * lanes_per_row + ch / 4) * 4 + (ch & 3)];
+            atomicAdd((which ? sum_gx : sum_g) + cg, a);
+        }
+    }
+}
+
 // Backward pass 2: grad_x = gamma*invstd*(g - sum_g/M - xhat*sum_gx/M)   (batch statistics)
 //                  grad_x = gamma*invstd*g                                (running statistics)
-__global__ void bn_act_bwd_apply_kernel(const float *__restrict__ x, const float *__restrict__ gy,
-                                        const float *__restrict__ mean, const float *__restrict__ invstd,
-                                        const float *__restrict__ gamma, const float *__restrict__ beta,
-                                        const float *__restrict__ sum_g, const float *__restrict__ sum_gx,
-                                        float slope, int use_batch_stats, int M, int C, long long total,
-                                        float *__restrict__ gx)
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
+    const float *__restrict__ x, const float *__restrict__ gy, const float *__restrict__ mean,
+    const float *__restrict__ invstd, const float *__restrict__ gamma, const float *__restrict__ beta,
+    const float *__restrict__ partial, int replicas, float slope, int use_batch_stats, int M, int C,
+    long long total, float *__restrict__ gx, float *__restrict__ dgamma, float *__restrict__ dbeta)
 {
+    // per-channel constants in LDS: k1 = gamma*invstd, then grad_x = k1*(g - a - xhat*b) with
+    // a = sum_g/M, b = sum_gxhat/M (zero in eval mode); totals of the replicas also go out as
+    // dbeta / dgamma (workgroup 0).
+    extern __shared__ float cs[];          // [6][C]: mean, invstd, gamma, beta, a, b
     const float invM = 1.0f / (float)M;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float sg = 0.f, sx = 0.f;
+        if (replicas == 8) {            // the host side's default: all 16 loads in flight at once
+            float pg[8], px[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                pg[r] = partial[(size_t)r * 2 * C + c];
+                px[r] = partial[(size_t)r * 2 * C + C + c];
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { sg += pg[r]; sx += px[r]; }
+        } else {
+            for (int r = 0; r < replicas; ++r) {
+                sg += partial[(size_t)r * 2 * C + c];
+                sx += partial[(size_t)r * 2 * C + C + c];
+            }
+        }
+        cs[c] = mean[c]; cs[C + c] = invstd[c]; cs[2 * C + c] = gamma[c]; cs[3 * C + c] = beta[c];
+        cs[4 * C + c] = use_batch_stats ? sg * invM : 0.f;
+        cs[5 * C + c] = use_batch_stats ? sx * invM : 0.f;
+        if (blockIdx.x == 0) {
+            if (dbeta) dbeta[c] = sg;
+            if (dgamma) dgamma[c] = sx;
+        }
+    }
+    __syncthreads();
+    const bool v4 = ((C & 3) == 0) && (((((uintptr_t)x | (uintptr_t)gy | (uintptr_t)gx)) & 15) == 0);
+    if (v4) {
+        const long long total4 = total / 4;
+        const int c4n = C / 4;
+        for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4;
+             i += (long long)gridDim.x * blockDim.x) {
+            const int c = (int)(i % c4n) * 4;
+            const float4 xv = reinterpret_cast<const float4 *>(x)[i];
+            const float4 gv = reinterpret_cast<const float4 *>(gy)[i];
+            const float xin[4] = {xv.x, xv.y, xv.z, xv.w}, gin[4] = {gv.x, gv.y, gv.z, gv.w};
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float is = cs[C + c + j], ga = cs[2 * C + c + j];
+                const float xh = (xin[j] - cs[c + j]) * is;
+                const float t = xh * ga + cs[3 * C + c + j];
+                const float g = t > 0.f ? gin[j] : gin[j] * slope;
+                o[j] = ga * is * (g - cs[4 * C + c + j] - xh * cs[5 * C + c + j]);
+            }
+            reinterpret_cast<float4 *>(gx)[i] = make_float4(o[0], o[1], o[2], o[3]);
+        }
+        return;
+    }
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C);
-        const float is = invstd[c], ga = gamma[c];
-        const float xh = (x[i] - mean[c]) * is;
-        const float t = xh * ga + beta[c];
-        float g = gy[i];
-        g = t > 0.f ? g : g * slope;
-        float d = use_batch_stats ? (g - sum_g[c] * invM - xh * (sum_gx[c] * invM)) : g;
-        gx[i] = ga * is * d;
+        const float is = cs[C + c], ga = cs[2 * C + c];
+        const float xh = (x[i] - cs[c]) * is;
+        const float t = xh * ga + cs[3 * C + c];
+        const float g = t > 0.f ? gy[i] : gy[i] * slope;
+        gx[i] = ga * is * (g - cs[4 * C + c] - xh * cs[5 * C + c]);
     }
 }
 
@@ -1009,31 +1119,49 @@ extern "C" int mpa_bn_act_fwd_f32(const float *x, const float *save_mean_invstd,
 
 extern "C" int mpa_bn_act_bwd_reduce_f32(const float *x, const float *grad_y, const float *mean, const float *invstd,
                                          const float *gamma, const float *beta, float slope, int M, int C,
-                                         float *sum_g, float *sum_gxhat, void *stream)
+                                         float *partial, int replicas, void *stream)
 {
     MPA_CLEAR_ERROR();
-    if (!x || !grad_y || !mean || !invstd || !gamma || !beta || !sum_g || !sum_gxhat || M <= 0 || C <= 0)
+    if (!x || !grad_y || !mean || !invstd || !gamma || !beta || !partial || replicas <= 0 || M <= 0 || C <= 0)
         return MPA_EINVAL;
-    dim3 grid;
-    int cpb, rpb;
-    slab_grid(M, C, grid, cpb, rpb);
-    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, grad_y, mean, invstd,
-                       gamma, beta, slope, M, C, cpb, rpb, sum_g, sum_gxhat);
+    const bool al = ((((uintptr_t)x | (uintptr_t)grad_y | (uintptr_t)mean | (uintptr_t)invstd | (uintptr_t)gamma |
+                       (uintptr_t)beta)) & 15) == 0;
+    if ((C & 3) == 0 && al) {
+        int lanes = C / 4;                                   // lanes per row: a divisor of 256
+        lanes = lanes >= 256 ? 256 : (lanes > 128 ? 256 : (lanes > 64 ? 128 : (lanes > 32 ? 64 : (lanes > 16 ? 32 : 16))));
+        const int gy_ = mpa_ceil_div(C / 4, lanes);
+        const int ry = 256 / lanes;
+        int want = 1024 / gy_;
+        int rpb = mpa_ceil_div(M, want < 1 ? 1 : want);
+        if (rpb < 2 * ry) rpb = 2 * ry;
+        hipLaunchKernelGGL(bn_act_bwd_reduce4_kernel, dim3(mpa_ceil_div(M, rpb), gy_), dim3(256), 0,
+                           (hipStream_t)stream, x, grad_y, mean, invstd, gamma, beta, slope, M, C, lanes, rpb, partial,
+                           replicas);
+    } else {
+        dim3 grid;
+        int cpb, rpb;
+        slab_grid(M, C, grid, cpb, rpb);
+        hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, grad_y, mean, invstd,
+                           gamma, beta, slope, M, C, cpb, rpb, partial, replicas);
+    }
     MPA_LAUNCH_CHECK();
     return MPA_OK;
 }
 
 extern "C" int mpa_bn_act_bwd_apply_f32(const float *x, const float *grad_y, const float *mean, const float *invstd,
-                                        const float *gamma, const float *beta, const float *sum_g,
-                                        const float *sum_gxhat, float slope, int use_batch_stats, int M, int C,
-                                        float *grad_x, void *stream)
+                                        const float *gamma, const float *beta, const float *partial, int replicas,
+                                        float slope, int use_batch_stats, int M, int C, float *grad_x, float *dgamma,
+                                        float *dbeta, void *stream)
 {
     MPA_CLEAR_ERROR();
-    if (!x || !grad_y || !mean || !invstd || !gamma || !beta || !grad_x || M <= 0 || C <= 0) return MPA_EINVAL;
-    if (use_batch_stats && (!sum_g || !sum_gxhat)) return MPA_EINVAL;
+    if (!x || !grad_y || !mean || !invstd || !gamma || !beta || !grad_x || !partial || replicas <= 0 || M <= 0 ||
+        C <= 0)
+        return MPA_EINVAL;
+    if (C > 8192) return MPA_EUNSUPPORTED;
     long long total = (long long)M * C;
-    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ew_grid(total)), dim3(EW_TPB), 0, (hipStream_t)stream, x, grad_y,
-                       mean, invstd, gamma, beta, sum_g, sum_gxhat, slope, use_batch_stats, M, C, total, grad_x);
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ew_grid(total / 4 + 1)), dim3(EW_TPB), 6 * C * sizeof(float),
+                       (hipStream_t)stream, x, grad_y, mean, invstd, gamma, beta, partial, replicas, slope,
+                       use_batch_stats, M, C, total, grad_x, dgamma, dbeta);
     MPA_LAUNCH_CHECK();
     return MPA_OK;
 }

@@ -638,6 +638,9 @@ def linear_kv(x, k_lin, v_lin):
     return kv.view(*lead, kv.shape[-1])
 
 
+_BN_REPLICAS = 8
+
+
 class _LinearBNAct(torch.autograd.Function):
     """Linear -> BatchNorm1d over the rows -> LeakyReLU (+ residual), as one unit: the GEMM epilogue
     yields the batch statistics, one elementwise kernel normalises + activates (+ adds the
@@ -655,11 +658,11 @@ class _LinearBNAct(torch.autograd.Function):
         saved = torch.empty(2, N, dtype=torch.float32, device=dev)
         direct = (_direct(W), _direct(b), _direct(gamma), _direct(beta))
         need = any(ctx.needs_input_grad)
-        own_sums = need and (direct[2] is None or direct[3] is None)
-        # sums: the [2][N] accumulator of backward's channel reductions, cleared here for free
-        sums = torch.empty(2, N, dtype=torch.float32, device=dev) if own_sums else None
+        # sums: [_BN_REPLICAS][2][N] accumulator of backward's channel reductions (float atomics spread
+        # over replicas), cleared here for free
+        sums = torch.empty(_BN_REPLICAS, 2, N, dtype=torch.float32, device=dev) if need else None
         _launch("mpa_bn_finalize_f32", _p(stats), M, N, _p(running_mean), _p(running_var), int(training),
-                float(momentum), float(eps), _p(saved), _p(sums), 2 * N, _p(nbt), _stream())
+                float(momentum), float(eps), _p(saved), _p(sums), _BN_REPLICAS * 2 * N, _p(nbt), _stream())
         _launch("mpa_bn_act_fwd_f32", _p(y), _p(saved), _p(gamma), _p(beta), _p(residual), float(slope), M, N,
                 _p(out), _stream())
         ctx.save_for_backward(x, W, y, gamma, beta, saved, sums)
@@ -677,18 +680,17 @@ class _LinearBNAct(torch.autograd.Function):
         N = W.shape[0]
         dev = x.device
         gout = gout.contiguous()
-        if sums is None:
-            sum_g, sum_gx = dbeta, dgamma              # accumulate straight into the flat gradients
-        else:
-            if ctx.ran_backward:        # double backward through the same node: accumulator is dirty
-                sums = torch.zeros(2, N, dtype=torch.float32, device=dev)
-            sum_g, sum_gx = sums[0], sums[1]
+        if ctx.ran_backward:            # double backward through the same node: accumulator is dirty
+            sums = torch.zeros(_BN_REPLICAS, 2, N, dtype=torch.float32, device=dev)
         ctx.ran_backward = True
         _launch("mpa_bn_act_bwd_reduce_f32", _p(y), _p(gout), _p(saved[0]), _p(saved[1]), _p(gamma), _p(beta), slope,
-                M, N, _p(sum_g), _p(sum_gx), _stream())
+                M, N, _p(sums), _BN_REPLICAS, _stream())
         gy = torch.empty(M, N, dtype=torch.float32, device=dev)
+        # dgamma / dbeta: stored by the apply pass, straight into the flat gradients when installed
+        gg = dgamma if dgamma is not None else torch.empty(N, dtype=torch.float32, device=dev)
+        gb_ = dbeta if dbeta is not None else torch.empty(N, dtype=torch.float32, device=dev)
         _launch("mpa_bn_act_bwd_apply_f32", _p(y), _p(gout), _p(saved[0]), _p(saved[1]), _p(gamma), _p(beta),
-                _p(sum_g), _p(sum_gx), slope, int(training), M, N, _p(gy), _stream())
+                _p(sums), _BN_REPLICAS, slope, int(training), M, N, _p(gy), _p(gg), _p(gb_), _stream())
         gx = gW = gb = None
         if ctx.needs_input_grad[0]:
             gx = torch.empty(M, K, dtype=torch.float32, device=dev)
@@ -707,8 +709,8 @@ class _LinearBNAct(torch.autograd.Function):
                 _col_sum_into(gy, db)
             else:
                 gb = _col_sum(gy)
-        ggamma = None if sums is None else sum_gx
-        gbeta = None if sums is None else sum_g
+        ggamma = None if dgamma is not None else gg
+        gbeta = None if dbeta is not None else gb_
         gres = gout if has_res else None
         return gx, gW, gb, ggamma, gbeta, None, None, None, gres, None, None, None, None
 
