@@ -84,13 +84,18 @@ int mpa_gather_bwd_f32(const float *grad_out, const int64_t *idx, int B, int N, 
 int mpa_diffattn_fwd_f32(const float *q, const float *k, const float *v, int ldkv,
                          const int64_t *idx, int B, int N, int S, int K, int C,
                          float *ctx, uint8_t *argk, void *stream);
-/* backward (closed form): recomputes the softmax; grad_q [B,S,C] is
- * written; grad_k / grad_v (leading dimension ldg, zeroed by the caller) are accumulated
- * through idx with float atomics. */
+/* backward (closed form): recomputes the softmax; grad_q [B,S,C] and
+ * grad_k / grad_v ([B,N,C] row views, leading dimension ldg) are all overwritten -- no clearing
+ * by the caller.  With a workspace of mpa_diffattn_bwd_workspace_bytes() the scatter through idx
+ * is done without float atomics (inverted neighbour table + per-slot gradients, summed per base
+ * row); with workspace == NULL (or too small, or a shape for which the size
+ * query returns 0) it falls back to global float atomics after clearing grad_k / grad_v. */
+size_t mpa_diffattn_bwd_workspace_bytes(int B, int N, int S, int K, int C);
 int mpa_diffattn_bwd_f32(const float *q, const float *k, const float *v, int ldkv,
                          const int64_t *idx, const uint8_t *argk, const float *grad_ctx,
                          int B, int N, int S, int K, int C,
-                         float *grad_q, float *grad_k, float *grad_v, int ldg, void *stream);
+                         float *grad_q, float *grad_k, float *grad_v, int ldg,
+                         void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- LocalTrans, xyz branch: modules/pointnet2_utils.py:518-544.  k and v are Linear(3->C)
  * applied to neighbour offsets, so the whole branch is one kernel on raw coordinates:

@@ -33,7 +33,9 @@ SIGNATURES = {
     "mpa_gather_fwd_f32": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "mpa_gather_bwd_f32": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "mpa_diffattn_fwd_f32": [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp],
-    "mpa_diffattn_bwd_f32": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp],
+    "mpa_diffattn_bwd_f32": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp,
+                             ctypes.c_size_t, _vp],
+    "mpa_diffattn_bwd_workspace_bytes": [_i, _i, _i, _i, _i],
     "mpa_diffattn_xyz_fwd_f32": [_vp] * 9 + [_i] * 5 + [_vp, _vp, _vp],
     "mpa_diffattn_xyz_bwd_f32": [_vp] * 11 + [_i] * 5 + [_vp] * 6 + [_vp],
     "mpa_gemm_f32": [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, ctypes.c_size_t, _vp],
@@ -64,6 +66,7 @@ for _name, _args in SIGNATURES.items():
     _fn = getattr(lib, _name)
     _fn.argtypes = _args
     _fn.restype = ctypes.c_int
+lib.mpa_diffattn_bwd_workspace_bytes.restype = ctypes.c_size_t
 lib.mpa_version.restype = ctypes.c_int
 lib.mpa_error_string.restype = ctypes.c_char_p
 lib.mpa_error_string.argtypes = [ctypes.c_int]

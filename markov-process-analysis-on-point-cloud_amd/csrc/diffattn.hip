@@ -81,6 +81,59 @@ __global__ __launch_bounds__(TPB) void diffattn_fwd_kernel(const float *__restri
     }
 }
 
+// float4 lanes: one lane owns 4 consecutive channels of a point, so every gathered row is read as
+// 16 B per lane (C % 4 == 0, 16-B aligned rows).
+template <int K_>
+__global__ __launch_bounds__(TPB) void diffattn_fwd_v4_kernel(const float *__restrict__ q, const float *__restrict__ kk,
+                                                              const float *__restrict__ vv, int ldkv,
+                                                              const int64_t *__restrict__ idx, int N, int S, int K,
+                                                              int C, float alpha, long long total4,
+                                                              float *__restrict__ ctx, uint8_t *__restrict__ argk)
+{
+    constexpr int KK = K_ > 0 ? K_ : KMAX;
+    const int k_ = K_ > 0 ? K_ : K;
+    const int c4n = C >> 2;
+    for (long long i = blockIdx.x * (long long)TPB + threadIdx.x; i < total4; i += (long long)gridDim.x * TPB) {
+        const long long p = i / c4n;
+        const int c = (int)(i - p * c4n) << 2;
+        const int b = (int)(p / S);
+        const int64_t *nb = idx + p * k_;
+        const float4 q4 = *reinterpret_cast<const float4 *>(q + p * C + c);
+        const float qv[4] = {q4.x, q4.y, q4.z, q4.w};
+        float4 k4[KK], v4[KK];
+#pragma unroll
+        for (int j = 0; j < KK; ++j)
+            if (j < k_) {
+                const long long row = ((long long)b * N + mpa_clamp_idx(nb[j], N)) * ldkv + c;
+                k4[j] = *reinterpret_cast<const float4 *>(kk + row);
+                v4[j] = *reinterpret_cast<const float4 *>(vv + row);
+            }
+        float best4[4];
+        uint8_t bj4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float e[KK], a[KK];
+#pragma unroll
+            for (int j = 0; j < KK; ++j)
+                if (j < k_) e[j] = (qv[u] - (&k4[j].x)[u]) * alpha;
+            float o;
+            softmax_offset<K_>(e, k_, a, o);
+            float best = (a[0] - o) * (&v4[0].x)[u];
+            int bj = 0;
+#pragma unroll
+            for (int j = 1; j < KK; ++j)
+                if (j < k_) {
+                    float t = (a[j] - o) * (&v4[j].x)[u];
+                    if (t > best) { best = t; bj = j; }
+                }
+            best4[u] = best;
+            bj4[u] = (uint8_t)bj;
+        }
+        *reinterpret_cast<float4 *>(ctx + p * C + c) = make_float4(best4[0], best4[1], best4[2], best4[3]);
+        *reinterpret_cast<uchar4 *>(argk + p * C + c) = make_uchar4(bj4[0], bj4[1], bj4[2], bj4[3]);
+    }
+}
+
 template <int K_>
 __global__ __launch_bounds__(TPB) void diffattn_bwd_kernel(const float *__restrict__ q, const float *__restrict__ kk,
                                                            const float *__restrict__ vv, int ldkv,
@@ -132,6 +185,296 @@ __global__ __launch_bounds__(TPB) void diffattn_bwd_kernel(const float *__restri
     }
 }
 
+// Backward without float atomics, in two passes over an inverted neighbour table.
+//   csr_build_kernel     per cloud: counting sort of the S*K (point, slot) entries by base row
+//                        -> rowptr [B][N+1], entries [B][S*K] (entry = s*K + j)
+//   diffattn_bwd_p1      lane = (point, channel) as in forward: recomputes the softmax, writes
+//                        grad_q and the per-slot key gradients T [B,S,K,C] and the value
+//                        gradient Tv [B,S,C] with plain coalesced stores
+//   diffattn_bwd_p2      lane = (base row, 4 channels): sums T over the row's entries (and Tv
+//                        where the entry's slot is the arg-max) -> grad_k, grad_v, fully written
+// (K+1) float atomics per (point, channel) -- 150 M per training step of the cls model -- ran at
+// the chip's atomic rate (~0.9 TB/s); an LDS-resident accumulator per (cloud, channel slice)
+// was no faster: ds_add_f32 retires about one lane per 2.5 clocks.
+constexpr int BWD_TPB = 1024;
+
+// One workgroup per (cloud, range of base rows): it scans all S*K entries of the cloud, counts
+// those of its rows in LDS (integer LDS atomics are as slow as the float ones, so the rows are
+// split over CSR_RANGES workgroups per cloud), counts the entries below its range for the global
+// offset, scans, fills and sorts its rows' lists.
+constexpr int CSR_TPB = 256;
+
+__device__ __forceinline__ int block_exclusive_scan(int v, int *wave_tot, int &total)
+{
+    // inclusive scan inside the wave (DPP-free shuffles; 4 waves)
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int x = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        int y = __shfl_up(x, off, 64);
+        if (lane >= off) x += y;
+    }
+    if (lane == 63) wave_tot[w] = x;
+    __syncthreads();
+    int base = 0;
+    total = 0;
+#pragma unroll
+    for (int i = 0; i < CSR_TPB / 64; ++i) {
+        if (i < w) base += wave_tot[i];
+        total += wave_tot[i];
+    }
+    __syncthreads();
+    return base + x - v;
+}
+
+__global__ __launch_bounds__(CSR_TPB) void csr_build_kernel(const int64_t *__restrict__ idx, int N, int SK, int range,
+                                                             int *__restrict__ rowptr, int *__restrict__ entries)
+{
+    extern __shared__ int csr_lds[];       // cnt[range] | pos[range]
+    __shared__ int wave_tot[CSR_TPB / 64];
+    constexpr int EPT = 32;                // entries per thread and chunk, all loads in flight at once
+    int *cnt = csr_lds, *pos = csr_lds + range;
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int r0 = blockIdx.x * range, r1 = min(N, r0 + range);
+    const int64_t *nb = idx + (size_t)b * SK;
+    int *rp = rowptr + (size_t)b * (N + 1);
+    int *en = entries + (size_t)b * SK;
+    for (int r = tid; r < range; r += CSR_TPB) cnt[r] = 0;
+    __syncthreads();
+    int rr[EPT];
+    const bool one_chunk = SK <= EPT * CSR_TPB;
+    int below = 0;
+    for (int base = 0; base < SK; base += EPT * CSR_TPB) {
+#pragma unroll
+        for (int u = 0; u < EPT; ++u) {
+            const int e = base + u * CSR_TPB + tid;
+            rr[u] = e < SK ? (int)mpa_clamp_idx(nb[e], N) : 0x7fffffff;
+        }
+#pragma unroll
+        for (int u = 0; u < EPT; ++u) {
+            below += rr[u] < r0;
+            if (rr[u] >= r0 && rr[u] < r1) atomicAdd(&cnt[rr[u] - r0], 1);
+        }
+    }
+    int nbelow;
+    block_exclusive_scan(below, wave_tot, nbelow);          // (syncs: cnt is complete afterwards)
+    // exclusive scan of cnt: thread t owns the contiguous chunk [t*per, (t+1)*per) of the range
+    const int per = (range + CSR_TPB - 1) / CSR_TPB;
+    int local = 0;
+    for (int r = tid * per; r < min(r1 - r0, (tid + 1) * per); ++r) local += cnt[r];
+    int tot;
+    int run = nbelow + block_exclusive_scan(local, wave_tot, tot);
+    for (int r = tid * per; r < min(r1 - r0, (tid + 1) * per); ++r) {
+        pos[r] = run;
+        rp[r0 + r] = run;
+        run += cnt[r];
+    }
+    if (r1 == N && tid == 0) rp[N] = SK;
+    __syncthreads();
+    // fill: entries of one row land in the order the LDS atomics retire (any order is a valid table)
+    for (int base = 0; base < SK; base += EPT * CSR_TPB) {
+        if (!one_chunk) {
+#pragma unroll
+            for (int u = 0; u < EPT; ++u) {
+                const int e = base + u * CSR_TPB + tid;
+                rr[u] = e < SK ? (int)mpa_clamp_idx(nb[e], N) : 0x7fffffff;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < EPT; ++u)
+            if (rr[u] >= r0 && rr[u] < r1) en[atomicAdd(&pos[rr[u] - r0], 1)] = base + u * CSR_TPB + tid;
+    }
+}
+
+template <int K_>
+__global__ __launch_bounds__(TPB) void diffattn_bwd_p1_kernel(
+    const float *__restrict__ q, const float *__restrict__ kk, const float *__restrict__ vv, int ldkv,
+    const int64_t *__restrict__ idx, const uint8_t *__restrict__ argk, const float *__restrict__ gctx, int N, int S,
+    int K, int C, float alpha, long long total, float *__restrict__ gq, float *__restrict__ T,
+    float *__restrict__ Tv)
+{
+    const int k_ = K_ > 0 ? K_ : K;
+    for (long long i = blockIdx.x * (long long)TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
+        long long p = i / C;
+        int c = (int)(i - p * C);
+        int b = (int)(p / S);
+        const int64_t *nb = idx + p * k_;
+        const float qv = q[i];
+        const int ks = argk[i];
+        const float g = gctx[i];
+        float e[K_ > 0 ? K_ : KMAX], a[K_ > 0 ? K_ : KMAX];
+        float vstar = 0.f;
+#pragma unroll
+        for (int j = 0; j < (K_ > 0 ? K_ : KMAX); ++j)
+            if (j < k_) {
+                long long r = ((long long)b * N + mpa_clamp_idx(nb[j], N)) * ldkv + c;
+                e[j] = (qv - kk[r]) * alpha;
+                if (j == ks) vstar = vv[r];
+            }
+        float o;
+        softmax_offset<K_>(e, k_, a, o);
+        float astar = 0.f;
+#pragma unroll
+        for (int j = 0; j < (K_ > 0 ? K_ : KMAX); ++j)
+            if (j < k_ && j == ks) astar = a[j];
+        const float h = g * vstar;
+        const float common = -1.0f - astar + o;
+        float dq = 0.f;
+        float *Tp = T + p * k_ * C + c;
+#pragma unroll
+        for (int j = 0; j < (K_ > 0 ? K_ : KMAX); ++j)
+            if (j < k_) {
+                float de = a[j] * h * ((j == ks ? 1.0f : 0.0f) + common);
+                dq += de;
+                Tp[(long long)j * C] = -alpha * de;
+            }
+        gq[i] = alpha * dq;
+        Tv[i] = g * (astar - o);
+    }
+}
+
+template <int K_>
+__global__ __launch_bounds__(TPB) void diffattn_bwd_p1_v4_kernel(
+    const float *__restrict__ q, const float *__restrict__ kk, const float *__restrict__ vv, int ldkv,
+    const int64_t *__restrict__ idx, const uint8_t *__restrict__ argk, const float *__restrict__ gctx, int N, int S,
+    int K, int C, float alpha, long long total4, float *__restrict__ gq, float *__restrict__ T,
+    float *__restrict__ Tv)
+{
+    constexpr int KK = K_ > 0 ? K_ : KMAX;
+    const int k_ = K_ > 0 ? K_ : K;
+    const int c4n = C >> 2;
+    for (long long i = blockIdx.x * (long long)TPB + threadIdx.x; i < total4; i += (long long)gridDim.x * TPB) {
+        const long long p = i / c4n;
+        const int c = (int)(i - p * c4n) << 2;
+        const int b = (int)(p / S);
+        const int64_t *nb = idx + p * k_;
+        const float4 q4 = *reinterpret_cast<const float4 *>(q + p * C + c);
+        const float4 g4 = *reinterpret_cast<const float4 *>(gctx + p * C + c);
+        const uchar4 ks4 = *reinterpret_cast<const uchar4 *>(argk + p * C + c);
+        const float qv[4] = {q4.x, q4.y, q4.z, q4.w}, gv_[4] = {g4.x, g4.y, g4.z, g4.w};
+        const int ks[4] = {ks4.x, ks4.y, ks4.z, ks4.w};
+        float4 k4[KK];
+        long long rows[KK];
+#pragma unroll
+        for (int j = 0; j < KK; ++j)
+            if (j < k_) {
+                rows[j] = ((long long)b * N + mpa_clamp_idx(nb[j], N)) * ldkv + c;
+                k4[j] = *reinterpret_cast<const float4 *>(kk + rows[j]);
+            }
+        float vstar[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            long long r = rows[0];
+#pragma unroll
+            for (int j = 1; j < KK; ++j)
+                if (j < k_ && j == ks[u]) r = rows[j];
+            vstar[u] = vv[r + u];
+        }
+        float de[KK][4], dq4[4], dv4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float e[KK], a[KK];
+#pragma unroll
+            for (int j = 0; j < KK; ++j)
+                if (j < k_) e[j] = (qv[u] - (&k4[j].x)[u]) * alpha;
+            float o;
+            softmax_offset<K_>(e, k_, a, o);
+            float astar = 0.f;
+#pragma unroll
+            for (int j = 0; j < KK; ++j)
+                if (j < k_ && j == ks[u]) astar = a[j];
+            const float h = gv_[u] * vstar[u];
+            const float common = -1.0f - astar + o;
+            float dq = 0.f;
+#pragma unroll
+            for (int j = 0; j < KK; ++j)
+                if (j < k_) {
+                    float d = a[j] * h * ((j == ks[u] ? 1.0f : 0.0f) + common);
+                    dq += d;
+                    de[j][u] = -alpha * d;
+                }
+            dq4[u] = alpha * dq;
+            dv4[u] = gv_[u] * (astar - o);
+        }
+        float *Tp = T + p * k_ * C + c;
+#pragma unroll
+        for (int j = 0; j < KK; ++j)
+            if (j < k_)
+                *reinterpret_cast<float4 *>(Tp + (long long)j * C) = make_float4(de[j][0], de[j][1], de[j][2], de[j][3]);
+        *reinterpret_cast<float4 *>(gq + p * C + c) = make_float4(dq4[0], dq4[1], dq4[2], dq4[3]);
+        *reinterpret_cast<float4 *>(Tv + p * C + c) = make_float4(dv4[0], dv4[1], dv4[2], dv4[3]);
+    }
+}
+
+// lane = (base row, V channels); rows_per_block = 256 / lanes_per_row; blockIdx.y = cloud, so the
+// cloud's bases are scalar and the per-lane offsets 32-bit (S*K*C < 2^31 checked by the host).
+template <int V>
+__global__ __launch_bounds__(TPB) void diffattn_bwd_p2_kernel(
+    const float *__restrict__ T, const float *__restrict__ Tv, const uint8_t *__restrict__ argk,
+    const int *__restrict__ rowptr, const int *__restrict__ entries, int N, int S, int K, int C, int lanes_per_row,
+    float *__restrict__ gk, float *__restrict__ gv, int ldg)
+{
+    const int rl = threadIdx.x / lanes_per_row, cl = threadIdx.x % lanes_per_row;
+    const int rpb = TPB / lanes_per_row;
+    const int b = blockIdx.y;
+    const int r = blockIdx.x * rpb + rl;
+    if (r >= N) return;
+    const int *rp = rowptr + (size_t)b * (N + 1);
+    const int beg = rp[r], end = rp[r + 1];
+    const int *en = entries + (size_t)b * S * K;
+    const float *Tb = T + (size_t)b * S * K * C;
+    const float *Tvb = Tv + (size_t)b * S * C;
+    const uint8_t *ab = argk + (size_t)b * S * C;
+    for (int c = cl * V; c < C; c += lanes_per_row * V) {
+        float ak[V], av[V];
+#pragma unroll
+        for (int u = 0; u < V; ++u) ak[u] = av[u] = 0.f;
+        for (int e0 = beg; e0 < end; e0 += 4) {
+            unsigned ent[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ent[u] = (unsigned)en[min(e0 + u, end - 1)];
+            if constexpr (V == 4) {
+                float4 t[4];
+                uchar4 am[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    t[u] = *reinterpret_cast<const float4 *>(Tb + (ent[u] * (unsigned)C + (unsigned)c));
+                    am[u] = *reinterpret_cast<const uchar4 *>(ab + ((ent[u] / (unsigned)K) * (unsigned)C + (unsigned)c));
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (e0 + u >= end) break;
+                    ak[0] += t[u].x; ak[1] += t[u].y; ak[2] += t[u].z; ak[3] += t[u].w;
+                    const unsigned s_ = ent[u] / (unsigned)K, j = ent[u] - s_ * (unsigned)K;
+                    if (am[u].x == j || am[u].y == j || am[u].z == j || am[u].w == j) {
+                        const float4 d = *reinterpret_cast<const float4 *>(Tvb + (s_ * (unsigned)C + (unsigned)c));
+                        if (am[u].x == j) av[0] += d.x;
+                        if (am[u].y == j) av[1] += d.y;
+                        if (am[u].z == j) av[2] += d.z;
+                        if (am[u].w == j) av[3] += d.w;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (e0 + u >= end) break;
+                    const unsigned s_ = ent[u] / (unsigned)K, j = ent[u] - s_ * (unsigned)K;
+                    ak[0] += Tb[ent[u] * (unsigned)C + (unsigned)c];
+                    if (ab[s_ * (unsigned)C + (unsigned)c] == j) av[0] += Tvb[s_ * (unsigned)C + (unsigned)c];
+                }
+            }
+        }
+        float *ok = gk + ((size_t)b * N + r) * ldg + c, *ov = gv + ((size_t)b * N + r) * ldg + c;
+        if constexpr (V == 4) {
+            *reinterpret_cast<float4 *>(ok) = make_float4(ak[0], ak[1], ak[2], ak[3]);
+            *reinterpret_cast<float4 *>(ov) = make_float4(av[0], av[1], av[2], av[3]);
+        } else {
+            ok[0] = ak[0];
+            ov[0] = av[0];
+        }
+    }
+}
+
 // ------------------------------------------------------------------ xyz branch
 // One lane = one output channel with its 12 projection weights in registers; the workgroup
 // walks points, whose centre / neighbour coordinates are wave-uniform.
@@ -178,29 +521,37 @@ __global__ __launch_bounds__(TPB) void diffattn_xyz_fwd_kernel(
     }
 }
 
+// Workgroup = PW point-lanes x bx channel-lanes (1024 threads): each point-lane walks points, a
+// lane keeps its channel's 18 partial gradients in registers; they meet in LDS (ds_add_f32) and
+// leave as one global atomic per (workgroup, value).
 template <int K_>
-__global__ __launch_bounds__(TPB) void diffattn_xyz_bwd_kernel(
+__global__ __launch_bounds__(BWD_TPB) void diffattn_xyz_bwd_kernel(
     const float *__restrict__ xyz, const float *__restrict__ center, const int64_t *__restrict__ idx,
     const float *__restrict__ Wq, const float *__restrict__ bq, const float *__restrict__ Wk,
     const float *__restrict__ bk, const float *__restrict__ Wv, const float *__restrict__ bv,
-    const uint8_t *__restrict__ argk, const float *__restrict__ gctx, int N, int S, int K, int C, float alpha,
-    long long npoints, float *__restrict__ gWq, float *__restrict__ gbq, float *__restrict__ gWk,
+    const uint8_t *__restrict__ argk, const float *__restrict__ gctx, int N, int S, int K, int C, int bx,
+    float alpha, long long npoints, float *__restrict__ gWq, float *__restrict__ gbq, float *__restrict__ gWk,
     float *__restrict__ gbk, float *__restrict__ gWv, float *__restrict__ gbv)
 {
+    __shared__ float red[12][256];
     const int k_ = K_ > 0 ? K_ : K;
-    const int c = blockIdx.y * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const float wq0 = Wq[c * 3], wq1 = Wq[c * 3 + 1], wq2 = Wq[c * 3 + 2], bqc = bq[c];
-    const float wk0 = Wk[c * 3], wk1 = Wk[c * 3 + 1], wk2 = Wk[c * 3 + 2], bkc = bk[c];
-    const float wv0 = Wv[c * 3], wv1 = Wv[c * 3 + 1], wv2 = Wv[c * 3 + 2], bvc = bv[c];
+    const int cl = threadIdx.x % bx, pw = threadIdx.x / bx, PW = blockDim.x / bx;
+    const int c = blockIdx.y * bx + cl;
+    const bool live = c < C;
+    const int cc = live ? c : C - 1;
+    for (int i = threadIdx.x; i < 12 * 256; i += blockDim.x) (&red[0][0])[i] = 0.f;
+    __syncthreads();
+    const float wq0 = Wq[cc * 3], wq1 = Wq[cc * 3 + 1], wq2 = Wq[cc * 3 + 2], bqc = bq[cc];
+    const float wk0 = Wk[cc * 3], wk1 = Wk[cc * 3 + 1], wk2 = Wk[cc * 3 + 2], bkc = bk[cc];
+    const float wv0 = Wv[cc * 3], wv1 = Wv[cc * 3 + 1], wv2 = Wv[cc * 3 + 2], bvc = bv[cc];
     float aq[4] = {0, 0, 0, 0}, ak[4] = {0, 0, 0, 0}, av[4] = {0, 0, 0, 0};   // (dW[0..2], db)
-    for (long long p = blockIdx.x; p < npoints; p += gridDim.x) {
+    for (long long p = (long long)blockIdx.x * PW + pw; p < npoints; p += (long long)gridDim.x * PW) {
         int b = (int)(p / S);
         const float cx = center[p * 3], cy = center[p * 3 + 1], cz = center[p * 3 + 2];
         const float qv = fmaf(wq2, cz, fmaf(wq1, cy, fmaf(wq0, cx, bqc)));
         const int64_t *nb = idx + p * k_;
-        const int ks = argk[p * C + c];
-        const float g = gctx[p * C + c];
+        const int ks = argk[p * C + cc];
+        const float g = gctx[p * C + cc];
         float e[K_ > 0 ? K_ : KMAX], a[K_ > 0 ? K_ : KMAX];
         float rx[K_ > 0 ? K_ : KMAX], ry[K_ > 0 ? K_ : KMAX], rz[K_ > 0 ? K_ : KMAX];
         float vstar = 0.f, sx = 0.f, sy = 0.f, sz = 0.f;
@@ -240,14 +591,23 @@ __global__ __launch_bounds__(TPB) void diffattn_xyz_bwd_kernel(
         av[0] = fmaf(dv, sx, av[0]); av[1] = fmaf(dv, sy, av[1]); av[2] = fmaf(dv, sz, av[2]); av[3] += dv;
     }
 #pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        atomicAdd(gWq + c * 3 + d, aq[d]);
-        atomicAdd(gWk + c * 3 + d, ak[d]);
-        atomicAdd(gWv + c * 3 + d, av[d]);
+    for (int d = 0; d < 4; ++d) {
+        atomicAdd(&red[d][cl], aq[d]);
+        atomicAdd(&red[4 + d][cl], ak[d]);
+        atomicAdd(&red[8 + d][cl], av[d]);
     }
-    atomicAdd(gbq + c, aq[3]);
-    atomicAdd(gbk + c, ak[3]);
-    atomicAdd(gbv + c, av[3]);
+    __syncthreads();
+    if (pw == 0 && live) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            atomicAdd(gWq + c * 3 + d, red[d][cl]);
+            atomicAdd(gWk + c * 3 + d, red[4 + d][cl]);
+            atomicAdd(gWv + c * 3 + d, red[8 + d][cl]);
+        }
+        atomicAdd(gbq + c, red[3][cl]);
+        atomicAdd(gbk + c, red[7][cl]);
+        atomicAdd(gbv + c, red[11][cl]);
+    }
 }
 
 inline int grid_for(long long total)
@@ -268,7 +628,13 @@ extern "C" int mpa_diffattn_fwd_f32(const float *q, const float *k, const float 
     long long total = (long long)B * S * C;
     float alpha = 1.0f / sqrtf((float)C);
     hipStream_t st = (hipStream_t)stream;
-    if (K == 8)
+    static const bool scalar_only = getenv("MPA_DIFFATTN_SCALAR") != nullptr;
+    const bool vec4 = !scalar_only && (C & 3) == 0 && (ldkv & 3) == 0 &&
+                      ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)ctx | (uintptr_t)argk)) & 15) == 0;
+    if (vec4 && K == 8)
+        hipLaunchKernelGGL(diffattn_fwd_v4_kernel<8>, dim3(grid_for(total / 4)), dim3(TPB), 0, st, q, k, v, ldkv, idx, N,
+                           S, K, C, alpha, total / 4, ctx, argk);
+    else if (K == 8)
         hipLaunchKernelGGL(diffattn_fwd_kernel<8>, dim3(grid_for(total)), dim3(TPB), 0, st, q, k, v, ldkv, idx, N, S, K,
                            C, alpha, total, ctx, argk);
     else
@@ -278,9 +644,36 @@ extern "C" int mpa_diffattn_fwd_f32(const float *q, const float *k, const float 
     return MPA_OK;
 }
 
+namespace {
+struct BwdWorkspace {
+    size_t t_off, tv_off, rowptr_off, entries_off, total;
+};
+inline BwdWorkspace bwd_workspace(int B, int N, int S, int K, int C)
+{
+    BwdWorkspace w;
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    w.t_off = 0;
+    w.tv_off = up((size_t)B * S * K * C * 4);
+    w.rowptr_off = w.tv_off + up((size_t)B * S * C * 4);
+    w.entries_off = w.rowptr_off + up((size_t)B * (N + 1) * 4);
+    w.total = w.entries_off + up((size_t)B * S * K * 4);
+    return w;
+}
+constexpr int CSR_MAX_N = 12288;       // 2N ints of LDS <= 96 KB for a single row range
+}  // namespace
+
+extern "C" size_t mpa_diffattn_bwd_workspace_bytes(int B, int N, int S, int K, int C)
+{
+    if (B <= 0 || N <= 0 || S <= 0 || K <= 0 || C <= 0 || N > CSR_MAX_N || (long long)S * K * C > 0x7fffffffLL ||
+        B > 65535)
+        return 0;
+    return bwd_workspace(B, N, S, K, C).total;
+}
+
 extern "C" int mpa_diffattn_bwd_f32(const float *q, const float *k, const float *v, int ldkv, const int64_t *idx,
                                     const uint8_t *argk, const float *grad_ctx, int B, int N, int S, int K, int C,
-                                    float *grad_q, float *grad_k, float *grad_v, int ldg, void *stream)
+                                    float *grad_q, float *grad_k, float *grad_v, int ldg, void *workspace,
+                                    size_t workspace_bytes, void *stream)
 {
     MPA_CLEAR_ERROR();
     if (!q || !k || !v || !idx || !argk || !grad_ctx || !grad_q || !grad_k || !grad_v || B <= 0 || N <= 0 || S <= 0 ||
@@ -290,6 +683,56 @@ extern "C" int mpa_diffattn_bwd_f32(const float *q, const float *k, const float 
     long long total = (long long)B * S * C;
     float alpha = 1.0f / sqrtf((float)C);
     hipStream_t st = (hipStream_t)stream;
+    const size_t need = mpa_diffattn_bwd_workspace_bytes(B, N, S, K, C);
+    static const bool force_atomic = getenv("MPA_DIFFATTN_ATOMIC") != nullptr;
+    if (workspace && need && workspace_bytes >= need && ((uintptr_t)workspace & 15) == 0 && !force_atomic) {
+        const BwdWorkspace w = bwd_workspace(B, N, S, K, C);
+        float *T = reinterpret_cast<float *>((char *)workspace + w.t_off);
+        float *Tv = reinterpret_cast<float *>((char *)workspace + w.tv_off);
+        int *rowptr = reinterpret_cast<int *>((char *)workspace + w.rowptr_off);
+        int *entries = reinterpret_cast<int *>((char *)workspace + w.entries_off);
+        int ranges = 1;                                       // workgroups per cloud: ~256 rows each, >= 256 in all
+        while (ranges < 64 && (N / ranges > 256 || B * ranges < 256) && N / (2 * ranges) >= 32) ranges <<= 1;
+        const int range = (N + ranges - 1) / ranges;
+        static int attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&csr_build_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              2 * CSR_MAX_N * (int)sizeof(int));
+        (void)attr;
+        hipLaunchKernelGGL(csr_build_kernel, dim3(mpa_ceil_div(N, range), B), dim3(CSR_TPB),
+                           (size_t)2 * range * sizeof(int), st, idx, N, S * K, range, rowptr, entries);
+        static const bool scalar_only = getenv("MPA_DIFFATTN_SCALAR") != nullptr;
+        const bool p1v4 = !scalar_only && (C & 3) == 0 && (ldkv & 3) == 0 &&
+                          ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)grad_ctx | (uintptr_t)grad_q |
+                             (uintptr_t)argk)) & 15) == 0;
+        if (p1v4 && K == 8)
+            hipLaunchKernelGGL(diffattn_bwd_p1_v4_kernel<8>, dim3(grid_for(total / 4)), dim3(TPB), 0, st, q, k, v, ldkv,
+                               idx, argk, grad_ctx, N, S, K, C, alpha, total / 4, grad_q, T, Tv);
+        else if (K == 8)
+            hipLaunchKernelGGL(diffattn_bwd_p1_kernel<8>, dim3(grid_for(total)), dim3(TPB), 0, st, q, k, v, ldkv, idx,
+                               argk, grad_ctx, N, S, K, C, alpha, total, grad_q, T, Tv);
+        else
+            hipLaunchKernelGGL(diffattn_bwd_p1_kernel<0>, dim3(grid_for(total)), dim3(TPB), 0, st, q, k, v, ldkv, idx,
+                               argk, grad_ctx, N, S, K, C, alpha, total, grad_q, T, Tv);
+        const bool v4 = (C & 3) == 0 && (ldg & 3) == 0 && ((((uintptr_t)grad_k | (uintptr_t)grad_v)) & 15) == 0;
+        const int per = v4 ? C / 4 : C;
+        int lanes = 1;
+        while (lanes < per && lanes < TPB) lanes <<= 1;                     // power of two: divides 256
+        const dim3 grid2(mpa_ceil_div(N, TPB / lanes), B);
+        if (v4)
+            hipLaunchKernelGGL(diffattn_bwd_p2_kernel<4>, grid2, dim3(TPB), 0, st, T, Tv, argk, rowptr, entries, N, S, K,
+                               C, lanes, grad_k, grad_v, ldg);
+        else
+            hipLaunchKernelGGL(diffattn_bwd_p2_kernel<1>, grid2, dim3(TPB), 0, st, T, Tv, argk, rowptr, entries, N, S, K,
+                               C, lanes, grad_k, grad_v, ldg);
+        MPA_LAUNCH_CHECK();
+        return MPA_OK;
+    }
+    // global-atomic kernel: clears the outputs first (grad_k | grad_v rows of C floats, stride ldg)
+    if (hipMemset2DAsync(grad_k, (size_t)ldg * 4, 0, (size_t)C * 4, (size_t)B * N, st) != hipSuccess ||
+        hipMemset2DAsync(grad_v, (size_t)ldg * 4, 0, (size_t)C * 4, (size_t)B * N, st) != hipSuccess) {
+        MPA_LAUNCH_CHECK();
+        return MPA_EHIP;
+    }
     if (K == 8)
         hipLaunchKernelGGL(diffattn_bwd_kernel<8>, dim3(grid_for(total)), dim3(TPB), 0, st, q, k, v, ldkv, idx, argk,
                            grad_ctx, N, S, K, C, alpha, total, grad_q, grad_k, grad_v, ldg);
@@ -337,16 +780,18 @@ extern "C" int mpa_diffattn_xyz_bwd_f32(const float *xyz, const float *center, c
         return MPA_EINVAL;
     if (K > KMAX) return MPA_EUNSUPPORTED;
     long long np = (long long)B * S;
-    int bx = C >= TPB ? TPB : ((C + 63) / 64) * 64;
-    dim3 grid((unsigned)(np > 1024 ? 1024 : np), mpa_ceil_div(C, bx));
+    int bx = C > 128 ? 256 : (C > 64 ? 128 : 64);           // channel lanes: a divisor of 1024
+    const int pw = BWD_TPB / bx;
+    long long gx = (np + pw - 1) / pw;
+    dim3 grid((unsigned)(gx > 512 ? 512 : gx), mpa_ceil_div(C, bx));
     float alpha = 1.0f / sqrtf((float)C);
     hipStream_t st = (hipStream_t)stream;
     if (K == 8)
-        hipLaunchKernelGGL(diffattn_xyz_bwd_kernel<8>, grid, dim3(bx), 0, st, xyz, center, idx, Wq, bq, Wk, bk, Wv, bv,
-                           argk, grad_ctx, N, S, K, C, alpha, np, gWq, gbq, gWk, gbk, gWv, gbv);
+        hipLaunchKernelGGL(diffattn_xyz_bwd_kernel<8>, grid, dim3(BWD_TPB), 0, st, xyz, center, idx, Wq, bq, Wk, bk, Wv,
+                           bv, argk, grad_ctx, N, S, K, C, bx, alpha, np, gWq, gbq, gWk, gbk, gWv, gbv);
     else
-        hipLaunchKernelGGL(diffattn_xyz_bwd_kernel<0>, grid, dim3(bx), 0, st, xyz, center, idx, Wq, bq, Wk, bk, Wv, bv,
-                           argk, grad_ctx, N, S, K, C, alpha, np, gWq, gbq, gWk, gbk, gWv, gbv);
+        hipLaunchKernelGGL(diffattn_xyz_bwd_kernel<0>, grid, dim3(BWD_TPB), 0, st, xyz, center, idx, Wq, bq, Wk, bk, Wv,
+                           bv, argk, grad_ctx, N, S, K, C, bx, alpha, np, gWq, gbq, gWk, gbk, gWv, gbv);
     MPA_LAUNCH_CHECK();
     return MPA_OK;
 }

@@ -305,9 +305,12 @@ class _DiffAttn(torch.autograd.Function):
         K = idx.shape[2]
         grad = grad.contiguous()
         gq = torch.empty_like(q)
-        gkv = torch.zeros_like(kv)
+        gkv = torch.empty_like(kv)          # fully written by the kernels
+        # per-slot gradients + inverted neighbour table: the atomic-free backward's scratch
+        need = int(lib.mpa_diffattn_bwd_workspace_bytes(B, N, S, K, C))
+        ws = torch.empty(need, dtype=torch.uint8, device=q.device) if need else None
         _launch("mpa_diffattn_bwd_f32", _p(q), _p(kv), _vp(kv.data_ptr() + 4 * C), 2 * C, _p(idx), _p(argk), _p(grad),
-                B, N, S, K, C, _p(gq), _p(gkv), _vp(gkv.data_ptr() + 4 * C), 2 * C, _stream(),
+                B, N, S, K, C, _p(gq), _p(gkv), _vp(gkv.data_ptr() + 4 * C), 2 * C, _p(ws), 0 if ws is None else ws.numel(), _stream(),
                 algo_bytes=B * S * (4 * (3 * C + 2 * K * C + C) + 8 * K + C))
         return gq, gkv, None
 
