@@ -15,6 +15,7 @@
 // balance of ~25, i.e. HBM-bound; the wide layers (512..2048) are MFMA-bound.
 #include "mpa_common.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -70,14 +71,27 @@ __device__ __forceinline__ void gemm_body(const int block_x, const int block_z, 
     const int kend = min(K, kbeg + kchunk);
     const int nslab = (kend - kbeg + KS - 1) / KS;
 
-    float4 ra[4], rb[4];
+    // two register sets: slab s+2 is requested while slab s is multiplied and slab s+1 (requested one
+    // iteration earlier) is written to LDS, so a request has two MFMA phases (~1.7 us) to land
+    float4 ra0[4], rb0[4], ra1[4], rb1[4];
     // ---- global -> registers for slab s (64 x 64 floats per operand = 4 float4 per lane)
-    auto load_slab = [&](int s) {
+    const bool m_full = m0 + TS <= M, n_full = n0 + TS <= N;
+    auto load_slab = [&](auto interior, int s, float4 (&ra)[4], float4 (&rb)[4]) {
+        constexpr bool INTERIOR = decltype(interior)::value;
         const int k0 = kbeg + s * KS;
+        // interior tiles (the usual case): 8 unconditional 16-B loads, all in flight together.  The
+        // edge path below is per-element predicated and the compiler serialises its loads.
+        if constexpr (INTERIOR) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int i = tid + NT * q;
-            {   // A
+            for (int q = 0; q < 4; ++q) {
+                const int i = tid + NT * q, r = i >> 4, c = (i & 15) * 4;
+                const float *p = TA ? A + (size_t)(k0 + r) * lda + m0 + c : A + (size_t)(m0 + r) * lda + k0 + c;
+                ra[q] = *reinterpret_cast<const float4 *>(p);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = tid + NT * q;
                 int r, c;            // r: row of the global matrix walked by this lane, c: 4-wide column start
                 int gr, gc;
                 bool rok;
@@ -97,7 +111,18 @@ __device__ __forceinline__ void gemm_body(const int block_x, const int block_z, 
                 }
                 ra[q] = v;
             }
-            {   // B
+        }
+        if constexpr (INTERIOR) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = tid + NT * q, r = i >> 4, c = (i & 15) * 4;
+                const float *p = TB ? B + (size_t)(n0 + r) * ldb + k0 + c : B + (size_t)(k0 + r) * ldb + n0 + c;
+                rb[q] = *reinterpret_cast<const float4 *>(p);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = tid + NT * q;
                 int r, c, gr, gc;
                 bool rok;
                 if (TB) { r = i >> 4; c = (i & 15) * 4; gr = n0 + r; gc = k0 + c; rok = gr < N; }
@@ -119,7 +144,7 @@ __device__ __forceinline__ void gemm_body(const int block_x, const int block_z, 
         }
     };
     // ---- registers -> LDS buffer
-    auto store_slab = [&](float *buf) {
+    auto store_slab = [&](float *buf, const float4 (&ra)[4], const float4 (&rb)[4]) {
         float *As = buf, *Bs = buf + KS * LDA;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -195,14 +220,7 @@ __device__ __forceinline__ void gemm_body(const int block_x, const int block_z, 
             }
         }
     } else {
-    if (nslab > 0) {
-        load_slab(0);
-        store_slab(lds);
-    }
-    __syncthreads();
-    for (int s = 0; s < nslab; ++s) {
-        float *buf = lds + (s & 1) * BUF;
-        if (s + 1 < nslab) load_slab(s + 1);          // in flight during this slab's MFMAs
+    auto multiply = [&](const float *buf) {
         const float *As = buf + (wave * 16 + half) * LDA;
         const float *Bs = buf + KS * LDA + (wave * 16 + half) * LDB;
 #pragma unroll
@@ -218,9 +236,34 @@ __device__ __forceinline__ void gemm_body(const int block_x, const int block_z, 
             asum0 += a0;
             asum1 += a1;
         }
-        if (s + 1 < nslab) store_slab(lds + ((s + 1) & 1) * BUF);
+    };
+    auto main_loop = [&](auto interior) {
+        if (nslab > 0) {
+            load_slab(interior, 0, ra0, rb0);
+            if (nslab > 1) load_slab(interior, 1, ra1, rb1);
+            store_slab(lds, ra0, rb0);
+        }
         __syncthreads();
-    }
+        for (int s = 0; s < nslab; s += 2) {
+            // even slab s in buffer 0; set 1 holds slab s+1; set 0 is free
+            if (s + 2 < nslab) load_slab(interior, s + 2, ra0, rb0);
+            multiply(lds);
+            if (s + 1 < nslab) store_slab(lds + BUF, ra1, rb1);
+            __syncthreads();
+            if (s + 1 < nslab) {
+                if (s + 3 < nslab) load_slab(interior, s + 3, ra1, rb1);
+                multiply(lds + BUF);
+                if (s + 2 < nslab) store_slab(lds, ra0, rb0);
+                __syncthreads();
+            }
+        }
+    };
+    // interior tiles (the usual case) run a loop whose 8 loads per slab are unconditional 16-B
+    // loads, all in flight together; the edge variant is per-element predicated
+    if (vecA && vecB && m_full && n_full && ((kend - kbeg) % KS) == 0)
+        main_loop(std::true_type{});
+    else
+        main_loop(std::false_type{});
 
     }   // LDS-staged main loop
 
