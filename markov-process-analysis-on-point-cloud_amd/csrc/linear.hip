@@ -38,7 +38,7 @@ __device__ __forceinline__ void gemm_body(const int block_x, const int block_z, 
                                           const float *__restrict__ B, int ldb, const float *__restrict__ bias,
                                           float *__restrict__ C, int ldc, int M, int N, int K, int kchunk,
                                           int out_mode, int vecA, int vecB, float *__restrict__ tile_stats,
-                                          float *__restrict__ zero_c, float *__restrict__ a_col_sum)
+                                          float *__restrict__ zero_c, float *__restrict__ a_col_sum, int tn_stream)
 {
     // out_mode 0: C = result (+bias);  1: atomicAdd into C;  2: split-K partial slab
     //             C + blockIdx.z*M*ldc (plain stores, summed by splitk_reduce_kernel).
@@ -174,7 +174,10 @@ __device__ __forceinline__ void gemm_body(const int block_x, const int block_z, 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    bool streamed = false;
     if constexpr (TA && !TB) {
+      if (tn_stream) {
+        streamed = true;
         // ---- k-major x k-major (weight gradients: dY^T [K][M] times X [K][N], K = B*S rows):
         // both MFMA operands are already laid out the way the instruction wants them -- for a
         // fixed k the 32 lanes of a half-wave read 32 consecutive floats (one 128-B line) -- so
@@ -219,7 +222,9 @@ __device__ __forceinline__ void gemm_body(const int block_x, const int block_z, 
                 }
             }
         }
-    } else {
+      }
+    }
+    if (!streamed) {
     auto multiply = [&](const float *buf) {
         const float *As = buf + (wave * 16 + half) * LDA;
         const float *Bs = buf + KS * LDA + (wave * 16 + half) * LDB;
@@ -419,10 +424,10 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const float *__restrict__ A
                                                      const float *__restrict__ bias, float *__restrict__ C, int ldc,
                                                      int M, int N, int K, int kchunk, int out_mode, int vecA,
                                                      int vecB, float *__restrict__ tile_stats, float *__restrict__ zero_c,
-                                                     float *__restrict__ a_col_sum)
+                                                     float *__restrict__ a_col_sum, int tn_stream)
 {
     gemm_body<TA, TB>(blockIdx.x, blockIdx.z, A, lda, B, ldb, bias, C, ldc, M, N, K, kchunk, out_mode, vecA, vecB,
-                      tile_stats, zero_c, a_col_sum);
+                      tile_stats, zero_c, a_col_sum, tn_stream);
 }
 
 // ---- grouped weight-gradient products: many independent small  out_p[M_p,N_p] = A_p^T B_p  (A_p, B_p
@@ -432,7 +437,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const float *__restrict__ A
 struct GroupedProblem {
     const float *A, *B;
     float *out, *a_col_sum, *slab;       // slab: split-K partial tiles [splits][M*N] (or nullptr: direct)
-    int lda, ldb, M, N, K, kchunk, splits, tiles;
+    int lda, ldb, M, N, K, kchunk, splits, tiles, vec, stream;
 };
 constexpr int GROUP_MAX = 40;
 struct GroupedArgs {
@@ -453,13 +458,13 @@ __global__ __launch_bounds__(NT, 2) void gemm_tn_grouped_kernel(const GroupedArg
     const GroupedProblem &q = args.p[which];
     const int local = blockIdx.x - args.block_start[which];
     const int tile = local % q.tiles, z = local / q.tiles;
-    const int vecA = 0, vecB = 0;        // unused by the streaming path
+    const int vecA = q.vec & 1, vecB = (q.vec >> 1) & 1;
     if (q.slab != nullptr)
         gemm_body<true, false>(tile, z, q.A, q.lda, q.B, q.ldb, nullptr, q.slab, q.N, q.M, q.N, q.K, q.kchunk, 2, vecA,
-                               vecB, nullptr, q.out, q.a_col_sum);
+                               vecB, nullptr, q.out, q.a_col_sum, q.stream);
     else
         gemm_body<true, false>(tile, z, q.A, q.lda, q.B, q.ldb, nullptr, q.out, q.N, q.M, q.N, q.K, q.kchunk, 0, vecA,
-                               vecB, nullptr, nullptr, q.a_col_sum);
+                               vecB, nullptr, nullptr, q.a_col_sum, q.stream);
 }
 
 // out_p[M*N] += sum_z slab_p[z][M*N] for all problems of a group (out_p cleared by the z = 0 tiles above)
@@ -499,11 +504,12 @@ int launch_gemm(const float *A, int lda, const float *B, int ldb, const float *b
                 int K, int splits, int kchunk, int out_mode, int vecA, int vecB, float *stats, float *zero_c,
                 float *a_col_sum, hipStream_t st)
 {
+    static const int tn_stream = getenv("MPA_TN_STREAM") ? atoi(getenv("MPA_TN_STREAM")) : 1;
     constexpr size_t lds = gemm_lds_bytes(TA, TB);
     static_assert(lds >= sizeof(float) * 4 * TS * TS && lds <= 64 * 1024, "reduction region fits, no opt-in");
     dim3 grid(mpa_ceil_div(M, TS) * mpa_ceil_div(N, TS), 1, splits);
     hipLaunchKernelGGL((gemm_kernel<TA, TB>), grid, dim3(NT), lds, st, A, lda, B, ldb, bias, C, ldc, M, N, K, kchunk,
-                       out_mode, vecA, vecB, stats, zero_c, a_col_sum);
+                       out_mode, vecA, vecB, stats, zero_c, a_col_sum, tn_stream);
     return MPA_OK;
 }
 
@@ -1051,10 +1057,16 @@ extern "C" int mpa_gemm_tn_grouped_f32(const MpaGemmTnProblem *problems, int cou
             q.lda = in.lda; q.ldb = in.ldb; q.M = in.M; q.N = in.N; q.K = in.K;
             q.tiles = mpa_ceil_div(in.M, TS) * mpa_ceil_div(in.N, TS);
             const size_t mn = (size_t)in.M * in.N;
+            static const int tn_stream = getenv("MPA_TN_STREAM") ? atoi(getenv("MPA_TN_STREAM")) : 1;
+            static const int target_wgs = getenv("MPA_TN_WGS") ? atoi(getenv("MPA_TN_WGS")) : 256;
+            static const int min_kchunk = getenv("MPA_TN_KCHUNK") ? atoi(getenv("MPA_TN_KCHUNK")) : 2048;
+            q.stream = tn_stream;
+            q.vec = ((in.lda & 3) == 0 && (reinterpret_cast<uintptr_t>(in.A) & 15) == 0 ? 1 : 0) |
+                    ((in.ldb & 3) == 0 && (reinterpret_cast<uintptr_t>(in.B) & 15) == 0 ? 2 : 0);
             int splits = 1;
-            if (q.tiles < 256 && in.K >= 512) {
-                splits = (512 + q.tiles - 1) / q.tiles;
-                if (splits > in.K / 256) splits = in.K / 256;
+            if (q.tiles < target_wgs / 2 && in.K >= 2 * min_kchunk) {
+                splits = (target_wgs + q.tiles - 1) / q.tiles;
+                if (splits > in.K / min_kchunk) splits = in.K / min_kchunk;
                 const size_t room = workspace ? (workspace_bytes - ws_used) / (mn * sizeof(float)) : 0;
                 if ((size_t)splits > room) splits = (int)room;
                 if (splits < 1) splits = 1;
