@@ -173,14 +173,15 @@ int mpa_col_sum_f32(const float *x, int M, int C, int ld, float *out, void *stre
  * partial [replicas][2][C] pre-zeroed, e.g. by mpa_bn_finalize_f32's zero_buf).  Pass 2 sums the
  * replicas, writes grad_x = gamma*invstd*(g - sum_g/M - xhat*sum_gxhat/M) (use_batch_stats != 0)
  * or gamma*invstd*g (running statistics), and stores dbeta = sum g, dgamma = sum g*xhat
- * (either may be NULL). */
+ * (either may be NULL).  grad_y rows have leading dimension ldg floats (a column block of a wider
+ * gradient, e.g. one input of a concatenation, is read in place); x and grad_x are dense [M,C]. */
 int mpa_bn_act_bwd_reduce_f32(const float *x, const float *grad_y, const float *mean, const float *invstd,
                               const float *gamma, const float *beta, float slope, int M, int C,
-                              float *partial, int replicas, void *stream);
+                              int ldg, float *partial, int replicas, void *stream);
 int mpa_bn_act_bwd_apply_f32(const float *x, const float *grad_y, const float *mean, const float *invstd,
                              const float *gamma, const float *beta, const float *partial, int replicas,
-                             float slope, int use_batch_stats, int M, int C, float *grad_x, float *dgamma,
-                             float *dbeta, void *stream);
+                             float slope, int use_batch_stats, int M, int C, int ldg, float *grad_x,
+                             float *dgamma, float *dbeta, void *stream);
 
 /* ---- upsample: the decoder's coarse->fine transition, modules/pointnet2_utils.py:13-50.
  * points [B,S,C], knn_idx [B,S,K] with values < Nf (= S*scale_ratio).  out [B,Nf,C] is the

@@ -44,8 +44,8 @@ SIGNATURES = {
     "mpa_col_stats_f32": [_vp, _i, _i, _vp, _vp, _vp],
     "mpa_bn_act_fwd_f32": [_vp, _vp, _vp, _vp, _vp, _f, _i, _i, _vp, _vp],
     "mpa_col_sum_f32": [_vp, _i, _i, _i, _vp, _vp],
-    "mpa_bn_act_bwd_reduce_f32": [_vp] * 6 + [_f, _i, _i, _vp, _i, _vp],
-    "mpa_bn_act_bwd_apply_f32": [_vp] * 7 + [_i, _f, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "mpa_bn_act_bwd_reduce_f32": [_vp] * 6 + [_f, _i, _i, _i, _vp, _i, _vp],
+    "mpa_bn_act_bwd_apply_f32": [_vp] * 7 + [_i, _f, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "mpa_scalar_add_f32": [_vp, _f, _vp],
     "mpa_adam_step_f32": [_vp, _vp, _vp, _vp, ctypes.c_longlong, _f, _f, _f, _f, _f, _vp, _vp],
     "mpa_upsample_mean_fwd_f32": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp],

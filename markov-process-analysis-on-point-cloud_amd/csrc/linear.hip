@@ -249,8 +249,21 @@ __device__ __forceinline__ void gemm_body(const int block_x, const int block_z, 
             store_slab(lds, ra0, rb0);
         }
         __syncthreads();
-        for (int s = 0; s < nslab; s += 2) {
-            // even slab s in buffer 0; set 1 holds slab s+1; set 0 is free
+        int s = 0;
+        // steady state (every load unconditional, so no value merges for the register allocator to
+        // resolve with copies that would wait on the loads): even slab s in buffer 0; set 1 holds
+        // slab s+1; set 0 is free
+        for (; s + 3 < nslab; s += 2) {
+            load_slab(interior, s + 2, ra0, rb0);
+            multiply(lds);
+            store_slab(lds + BUF, ra1, rb1);
+            __syncthreads();
+            load_slab(interior, s + 3, ra1, rb1);
+            multiply(lds + BUF);
+            store_slab(lds, ra0, rb0);
+            __syncthreads();
+        }
+        for (; s < nslab; s += 2) {                 // the last 1..3 slabs
             if (s + 2 < nslab) load_slab(interior, s + 2, ra0, rb0);
             multiply(lds);
             if (s + 1 < nslab) store_slab(lds + BUF, ra1, rb1);
@@ -590,11 +603,11 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float *__restri
                                                            float *__restrict__ zero_me, int zero_n,
                                                            long long *__restrict__ num_batches_tracked)
 {
-    // 1024 lanes = 16 tile-groups x 64 channels: up to 1024 tiles per channel are summed as 16
-    // interleaved partial chains (4 independent loads in flight each), then combined in LDS in a
-    // fixed order -> deterministic.
-    __shared__ float red[16][64];
-    __shared__ float mean_s[64];
+    // 1024 lanes = 16 tile-groups x 64 channels.  Each lane folds its tiles (t = g, g+16, ...) into
+    // one (count, mean, M2) triple with Chan's pairwise update -- one pass, 16 tiles' (sum, M2) pairs
+    // loaded together -- and the 16 triples of a channel are merged in LDS in a fixed order:
+    // deterministic, and no E[y^2] - E[y]^2 cancellation anywhere.
+    __shared__ float red_n[16][64], red_mu[16][64], red_m2[16][64];
     const int tid = threadIdx.x, cl = tid & 63, g = tid >> 6;
     const int c = blockIdx.x * 64 + cl;
     if (blockIdx.x == 0) {
@@ -610,48 +623,46 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float *__restri
     }
     const int tiles = (M + TS - 1) / TS;
     const size_t st = (size_t)2 * C;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    float an = 0.f, amu = 0.f, am2 = 0.f;
+    auto merge = [&](float bn, float bmu, float bm2) {
+        const float n = an + bn;
+        const float d = bmu - amu;
+        const float w = __fdividef(bn, n);          // a weight in (0,1]: 2-ulp division is ample
+        amu = fmaf(d, w, amu);
+        am2 = am2 + bm2 + d * d * an * w;
+        an = n;
+    };
     if (c < C) {
-        int t = g;
-        for (; t + 48 < tiles; t += 64) {
-            s0 += tile_stats[(size_t)t * st + c];
-            s1 += tile_stats[(size_t)(t + 16) * st + c];
-            s2 += tile_stats[(size_t)(t + 32) * st + c];
-            s3 += tile_stats[(size_t)(t + 48) * st + c];
-        }
-        for (; t < tiles; t += 16) s0 += tile_stats[(size_t)t * st + c];
-    }
-    red[g][cl] = (s0 + s1) + (s2 + s3);
-    __syncthreads();
-    if (g == 0) {
-        float s = 0.f;
+        constexpr int U = 16;
+        for (int base = g; base < tiles; base += 16 * U) {
+            float sm[U], sq[U];
 #pragma unroll
-        for (int y = 0; y < 16; ++y) s += red[y][cl];
-        mean_s[cl] = s / (float)M;
-    }
-    __syncthreads();
-    const float mean = mean_s[cl];
-    float m0 = 0.f, m1 = 0.f, m2_ = 0.f, m3 = 0.f;
-    if (c < C) {
-        auto term = [&](int t) {
-            const float nt = (float)min(TS, M - t * TS);
-            const float d = tile_stats[(size_t)t * st + c] / nt - mean;
-            return tile_stats[(size_t)t * st + C + c] + nt * d * d;
-        };
-        int t = g;
-        for (; t + 48 < tiles; t += 64) {
-            m0 += term(t); m1 += term(t + 16); m2_ += term(t + 32); m3 += term(t + 48);
+            for (int u = 0; u < U; ++u) {
+                const int t = min(base + 16 * u, tiles - 1);       // clamped: unconditional loads
+                sm[u] = tile_stats[(size_t)t * st + c];
+                sq[u] = tile_stats[(size_t)t * st + C + c];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int t = base + 16 * u;
+                if (t < tiles) {
+                    const int rows = min(TS, M - t * TS);
+                    const float nt = (float)rows;
+                    // full tiles: * 2^-6 is exact; only the last, partial tile divides
+                    merge(nt, rows == TS ? sm[u] * (1.0f / TS) : sm[u] / nt, sq[u]);
+                }
+            }
         }
-        for (; t < tiles; t += 16) m0 += term(t);
     }
-    __syncthreads();
-    red[g][cl] = (m0 + m1) + (m2_ + m3);
+    red_n[g][cl] = an; red_mu[g][cl] = amu; red_m2[g][cl] = am2;
     __syncthreads();
     if (g == 0 && c < C) {
-        float m2 = 0.f;
+        an = 0.f; amu = 0.f; am2 = 0.f;
 #pragma unroll
-        for (int y = 0; y < 16; ++y) m2 += red[y][cl];
-        const float var = m2 / (float)M;
+        for (int y = 0; y < 16; ++y)
+            if (red_n[y][cl] > 0.f) merge(red_n[y][cl], red_mu[y][cl], red_m2[y][cl]);
+        const float mean = amu;
+        const float var = am2 / (float)M;
         save[c] = mean;
         save[C + c] = 1.0f / sqrtf(var + eps);
         if (running_mean) {
@@ -777,14 +788,14 @@ __device__ __forceinline__ void slab_reduce2(int M, int C, int cpb, int rows_per
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(
     const float *__restrict__ x, const float *__restrict__ gy, const float *__restrict__ mean,
     const float *__restrict__ invstd, const float *__restrict__ gamma, const float *__restrict__ beta, float slope,
-    int M, int C, int cpb, int rows_per_block, float *__restrict__ partial, int replicas)
+    int M, int C, int ldg, int cpb, int rows_per_block, float *__restrict__ partial, int replicas)
 {
     float *sum_g = partial + (size_t)(blockIdx.x % replicas) * 2 * C;
     float *sum_gx = sum_g + C;
     slab_reduce2(M, C, cpb, rows_per_block, sum_g, sum_gx, [&](int r, int c, float &sg, float &sgx) {
         const float xh = (x[(size_t)r * C + c] - mean[c]) * invstd[c];
         const float t = xh * gamma[c] + beta[c];
-        float g = gy[(size_t)r * C + c];
+        float g = gy[(size_t)r * ldg + c];
         g = t > 0.f ? g : g * slope;
         sg += g;
         sgx = fmaf(g, xh, sgx);
@@ -797,7 +808,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce4_kernel(
     const float *__restrict__ x, const float *__restrict__ gy, const float *__restrict__ mean,
     const float *__restrict__ invstd, const float *__restrict__ gamma, const float *__restrict__ beta, float slope,
-    int M, int C, int lanes_per_row, int rows_per_block, float *__restrict__ partial, int replicas)
+    int M, int C, int ldg, int lanes_per_row, int rows_per_block, float *__restrict__ partial, int replicas)
 {
     // partial [replicas][2][C] (pre-zeroed): workgroups spread their atomics over the replicas so
     // that at most gridDim.x/replicas of them add into one address; the apply pass sums them.
@@ -822,15 +833,15 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce4_kernel(
         int r = r0 + ry;
         for (; r + RY < r1; r += 2 * RY) {
             const float4 x0 = *reinterpret_cast<const float4 *>(x + (size_t)r * C + c);
-            const float4 g0 = *reinterpret_cast<const float4 *>(gy + (size_t)r * C + c);
+            const float4 g0 = *reinterpret_cast<const float4 *>(gy + (size_t)r * ldg + c);
             const float4 x1 = *reinterpret_cast<const float4 *>(x + (size_t)(r + RY) * C + c);
-            const float4 g1 = *reinterpret_cast<const float4 *>(gy + (size_t)(r + RY) * C + c);
+            const float4 g1 = *reinterpret_cast<const float4 *>(gy + (size_t)(r + RY) * ldg + c);
             acc1(x0, g0);
             acc1(x1, g1);
         }
         for (; r < r1; r += RY)
             acc1(*reinterpret_cast<const float4 *>(x + (size_t)r * C + c),
-                 *reinterpret_cast<const float4 *>(gy + (size_t)r * C + c));
+                 *reinterpret_cast<const float4 *>(gy + (size_t)r * ldg + c));
     }
     red[0][tid] = sg;
     red[1][tid] = sx;
@@ -854,7 +865,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce4_kernel(
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
     const float *__restrict__ x, const float *__restrict__ gy, const float *__restrict__ mean,
     const float *__restrict__ invstd, const float *__restrict__ gamma, const float *__restrict__ beta,
-    const float *__restrict__ partial, int replicas, float slope, int use_batch_stats, int M, int C,
+    const float *__restrict__ partial, int replicas, float slope, int use_batch_stats, int M, int C, int ldg,
     long long total, float *__restrict__ gx, float *__restrict__ dgamma, float *__restrict__ dbeta)
 {
     // per-channel constants in LDS: k1 = gamma*invstd, then grad_x = k1*(g - a - xhat*b) with
@@ -888,15 +899,16 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
         }
     }
     __syncthreads();
-    const bool v4 = ((C & 3) == 0) && (((((uintptr_t)x | (uintptr_t)gy | (uintptr_t)gx)) & 15) == 0);
+    const bool v4 = ((C & 3) == 0) && ((ldg & 3) == 0) && (((((uintptr_t)x | (uintptr_t)gy | (uintptr_t)gx)) & 15) == 0);
     if (v4) {
         const long long total4 = total / 4;
         const int c4n = C / 4;
         for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4;
              i += (long long)gridDim.x * blockDim.x) {
-            const int c = (int)(i % c4n) * 4;
+            const long long row = i / c4n;
+            const int c = (int)(i - row * c4n) * 4;
             const float4 xv = reinterpret_cast<const float4 *>(x)[i];
-            const float4 gv = reinterpret_cast<const float4 *>(gy)[i];
+            const float4 gv = *reinterpret_cast<const float4 *>(gy + row * ldg + c);
             const float xin[4] = {xv.x, xv.y, xv.z, xv.w}, gin[4] = {gv.x, gv.y, gv.z, gv.w};
             float o[4];
 #pragma unroll
@@ -913,11 +925,13 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
     }
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C);
+        const long long row = i / C;
+        const int c = (int)(i - row * C);
         const float is = cs[C + c], ga = cs[2 * C + c];
         const float xh = (x[i] - cs[c]) * is;
         const float t = xh * ga + cs[3 * C + c];
-        const float g = t > 0.f ? gy[i] : gy[i] * slope;
+        const float g0 = gy[row * ldg + c];
+        const float g = t > 0.f ? g0 : g0 * slope;
         gx[i] = ga * is * (g - cs[4 * C + c] - xh * cs[5 * C + c]);
     }
 }
@@ -1174,14 +1188,15 @@ extern "C" int mpa_bn_act_fwd_f32(const float *x, const float *save_mean_invstd,
 
 extern "C" int mpa_bn_act_bwd_reduce_f32(const float *x, const float *grad_y, const float *mean, const float *invstd,
                                          const float *gamma, const float *beta, float slope, int M, int C,
-                                         float *partial, int replicas, void *stream)
+                                         int ldg, float *partial, int replicas, void *stream)
 {
     MPA_CLEAR_ERROR();
-    if (!x || !grad_y || !mean || !invstd || !gamma || !beta || !partial || replicas <= 0 || M <= 0 || C <= 0)
+    if (!x || !grad_y || !mean || !invstd || !gamma || !beta || !partial || replicas <= 0 || M <= 0 || C <= 0 ||
+        ldg < C)
         return MPA_EINVAL;
     const bool al = ((((uintptr_t)x | (uintptr_t)grad_y | (uintptr_t)mean | (uintptr_t)invstd | (uintptr_t)gamma |
                        (uintptr_t)beta)) & 15) == 0;
-    if ((C & 3) == 0 && al) {
+    if ((C & 3) == 0 && (ldg & 3) == 0 && al) {
         int lanes = C / 4;                                   // lanes per row: a divisor of 256
         lanes = lanes >= 256 ? 256 : (lanes > 128 ? 256 : (lanes > 64 ? 128 : (lanes > 32 ? 64 : (lanes > 16 ? 32 : 16))));
         const int gy_ = mpa_ceil_div(C / 4, lanes);
@@ -1190,14 +1205,14 @@ extern "C" int mpa_bn_act_bwd_reduce_f32(const float *x, const float *grad_y, co
         int rpb = mpa_ceil_div(M, want < 1 ? 1 : want);
         if (rpb < 2 * ry) rpb = 2 * ry;
         hipLaunchKernelGGL(bn_act_bwd_reduce4_kernel, dim3(mpa_ceil_div(M, rpb), gy_), dim3(256), 0,
-                           (hipStream_t)stream, x, grad_y, mean, invstd, gamma, beta, slope, M, C, lanes, rpb, partial,
+                           (hipStream_t)stream, x, grad_y, mean, invstd, gamma, beta, slope, M, C, ldg, lanes, rpb, partial,
                            replicas);
     } else {
         dim3 grid;
         int cpb, rpb;
         slab_grid(M, C, grid, cpb, rpb);
         hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, grad_y, mean, invstd,
-                           gamma, beta, slope, M, C, cpb, rpb, partial, replicas);
+                           gamma, beta, slope, M, C, ldg, cpb, rpb, partial, replicas);
     }
     MPA_LAUNCH_CHECK();
     return MPA_OK;
@@ -1205,18 +1220,18 @@ extern "C" int mpa_bn_act_bwd_reduce_f32(const float *x, const float *grad_y, co
 
 extern "C" int mpa_bn_act_bwd_apply_f32(const float *x, const float *grad_y, const float *mean, const float *invstd,
                                         const float *gamma, const float *beta, const float *partial, int replicas,
-                                        float slope, int use_batch_stats, int M, int C, float *grad_x, float *dgamma,
-                                        float *dbeta, void *stream)
+                                        float slope, int use_batch_stats, int M, int C, int ldg, float *grad_x,
+                                        float *dgamma, float *dbeta, void *stream)
 {
     MPA_CLEAR_ERROR();
     if (!x || !grad_y || !mean || !invstd || !gamma || !beta || !grad_x || !partial || replicas <= 0 || M <= 0 ||
-        C <= 0)
+        C <= 0 || ldg < C)
         return MPA_EINVAL;
     if (C > 8192) return MPA_EUNSUPPORTED;
     long long total = (long long)M * C;
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ew_grid(total / 4 + 1)), dim3(EW_TPB), 6 * C * sizeof(float),
                        (hipStream_t)stream, x, grad_y, mean, invstd, gamma, beta, partial, replicas, slope,
-                       use_batch_stats, M, C, total, grad_x, dgamma, dbeta);
+                       use_batch_stats, M, C, ldg, total, grad_x, dgamma, dbeta);
     MPA_LAUNCH_CHECK();
     return MPA_OK;
 }

@@ -79,10 +79,13 @@ class LocalTrans(nn.Module):
         self.ffn = Linear(out_c, out_c, bn=False)
         self.tanh = nn.Tanh()
 
-    def forward(self, features, idx, pos, FPS_idx=None, xyz=False):
+    def forward(self, features, idx, pos, FPS_idx=None, xyz=False, center=None):
+        # `center` (optional, not in the reference signature): index_points(features, FPS_idx) when
+        # the caller already has it (LocalMerge gathers it once for both feature streams and the kNN)
         if self.usetanh:
             raise NotImplementedError("usetanh=True is dead code in the reference models (always False)")
-        center = index_points(features, FPS_idx) if FPS_idx is not None else features
+        if center is None:
+            center = index_points(features, FPS_idx) if FPS_idx is not None else features
         residual = self.conv_res(center) if self.residual else center
         if xyz:
             context = ops.diffattn_xyz(features, center, idx, self.q.weight, self.q.bias, self.k.weight,
@@ -118,8 +121,8 @@ class LocalMerge(nn.Module):
             fs = feature if FPS_idx is None else index_points(feature, FPS_idx)
             _, idx_feature = knn_point(self.knn, feature, fs)
             xyz_f = self.xyz_Trans(features=base_xyz, idx=idx, pos=base_xyz, FPS_idx=FPS_idx, xyz=True)
-            f1 = self.feature_Trans1(features=feature, idx=idx, pos=base_xyz, FPS_idx=FPS_idx)
-            f2 = self.feature_Trans2(features=feature, idx=idx_feature, pos=base_xyz, FPS_idx=FPS_idx)
+            f1 = self.feature_Trans1(features=feature, idx=idx, pos=base_xyz, FPS_idx=FPS_idx, center=fs)
+            f2 = self.feature_Trans2(features=feature, idx=idx_feature, pos=base_xyz, FPS_idx=FPS_idx, center=fs)
             merge_features = self.fc2(torch.cat((xyz_f, f1, f2), dim=2))
         if FPS_idx is not None:
             normal = index_points(normal, FPS_idx)

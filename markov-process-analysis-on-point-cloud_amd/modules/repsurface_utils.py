@@ -109,8 +109,8 @@ class LocalMerge(nn.Module):
         else:
             fs = feature if FPS_idx is None else index_points(feature, FPS_idx)
             _, idx_feature = knn_point(self.knn, feature, fs)
-            f1 = self.feature_Trans(features=feature, idx=idx, pos=base_xyz, FPS_idx=FPS_idx)
-            f2 = self.feature_Trans2(features=feature, idx=idx_feature, pos=base_xyz, FPS_idx=FPS_idx)
+            f1 = self.feature_Trans(features=feature, idx=idx, pos=base_xyz, FPS_idx=FPS_idx, center=fs)
+            f2 = self.feature_Trans2(features=feature, idx=idx_feature, pos=base_xyz, FPS_idx=FPS_idx, center=fs)
             merge_features = self.fc2(torch.cat((f1, f2), dim=2))
         return merge_features, normal, idx, dist
 

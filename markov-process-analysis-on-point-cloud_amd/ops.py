@@ -534,6 +534,15 @@ def _direct(t):
     return getattr(t, "_mpa_grad_buf", None) if t is not None else None
 
 
+def _rows_ld(t):
+    """2-D gradient as (tensor, leading dimension): a column block of a wider row-major tensor (one
+    input of a concatenation) is used in place, anything else is made contiguous."""
+    if t.stride(1) == 1 and t.stride(0) >= t.shape[1] and t.data_ptr() % 16 == 0:
+        return t, t.stride(0)
+    t = t.contiguous()
+    return t, t.shape[1]
+
+
 class _Linear(torch.autograd.Function):
     """y[M,N] = x[M,K] W[N,K]^T + b on the fp32-MFMA GEMM; backward = two more GEMMs.
     bias_grad_is_zero: the caller knows the bias gradient vanishes identically (q / k projections
@@ -556,12 +565,12 @@ class _Linear(torch.autograd.Function):
         x, W = ctx.saved_tensors
         M, K = x.shape
         N = W.shape[0]
-        gy = gy.contiguous()
+        gy, ldg = _rows_ld(gy)
         dW, db = ctx.direct
         gx = gW = gb = None
         if ctx.needs_input_grad[0]:
             gx = torch.empty(M, K, dtype=torch.float32, device=x.device)
-            _gemm(gy, N, 0, W, K, 0, None, gx, K, M, K, N)            # gy [M,N] @ W [N,K]
+            _gemm(gy, ldg, 0, W, K, 0, None, gx, K, M, K, N)          # gy [M,N] @ W [N,K]
         want_b = ctx.has_bias and ctx.needs_input_grad[2] and not ctx.zero_bias
         gb_buf = None
         if want_b:
@@ -569,11 +578,11 @@ class _Linear(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             gW = dW if dW is not None else torch.empty(N, K, dtype=torch.float32, device=x.device)
             # gy^T [N,M] @ x [M,K]; the bias gradient (column sums of gy) rides along
-            _weight_grad(gy, N, x, K, gW, N, K, M, a_col_sum=gb_buf, direct=dW is not None and (gb_buf is None or db is not None))
+            _weight_grad(gy, ldg, x, K, gW, N, K, M, a_col_sum=gb_buf, direct=dW is not None and (gb_buf is None or db is not None))
             if dW is not None:
                 gW = None
         elif want_b:
-            _col_sum_into(gy, gb_buf)
+            _col_sum_into(gy, gb_buf, ld=ldg)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             if ctx.zero_bias:
                 gb = None if db is not None else _zeros_like_cached(x.device, N)
@@ -682,18 +691,18 @@ class _LinearBNAct(torch.autograd.Function):
         M, K = x.shape
         N = W.shape[0]
         dev = x.device
-        gout = gout.contiguous()
+        gout, ldg = _rows_ld(gout)
         if ctx.ran_backward:            # double backward through the same node: accumulator is dirty
             sums = torch.zeros(_BN_REPLICAS, 2, N, dtype=torch.float32, device=dev)
         ctx.ran_backward = True
         _launch("mpa_bn_act_bwd_reduce_f32", _p(y), _p(gout), _p(saved[0]), _p(saved[1]), _p(gamma), _p(beta), slope,
-                M, N, _p(sums), _BN_REPLICAS, _stream())
+                M, N, ldg, _p(sums), _BN_REPLICAS, _stream())
         gy = torch.empty(M, N, dtype=torch.float32, device=dev)
         # dgamma / dbeta: stored by the apply pass, straight into the flat gradients when installed
         gg = dgamma if dgamma is not None else torch.empty(N, dtype=torch.float32, device=dev)
         gb_ = dbeta if dbeta is not None else torch.empty(N, dtype=torch.float32, device=dev)
         _launch("mpa_bn_act_bwd_apply_f32", _p(y), _p(gout), _p(saved[0]), _p(saved[1]), _p(gamma), _p(beta),
-                _p(sums), _BN_REPLICAS, slope, int(training), M, N, _p(gy), _p(gg), _p(gb_), _stream())
+                _p(sums), _BN_REPLICAS, slope, int(training), M, N, ldg, _p(gy), _p(gg), _p(gb_), _stream())
         gx = gW = gb = None
         if ctx.needs_input_grad[0]:
             gx = torch.empty(M, K, dtype=torch.float32, device=dev)

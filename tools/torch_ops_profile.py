@@ -15,19 +15,20 @@ args = argparse.Namespace(num_point=1024, return_dist=True, cuda_ops=True, num_c
 model = Model(args).to(dev).train()
 crit = SmoothClsLoss()
 x, y = synthetic_batch(64, 1234, dev)
-red = GradReducer(model); red.overlap = False
+red = GradReducer(model, direct=True); red.overlap = False
 def step():
     red.zero_grad(); loss = crit(model(x), y); loss.backward(); red.all_reduce()
 for _ in range(3): step()
 torch.cuda.synchronize()
 from torch.profiler import profile, ProfilerActivity
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=False) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
     step(); torch.cuda.synchronize()
 rows = []
-for e in prof.key_averages():
+for e in prof.key_averages(group_by_stack_n=12):
     dt = getattr(e, "device_time_total", None) or getattr(e, "cuda_time_total", 0)
     if dt > 0 and e.key.startswith("aten::"):
-        rows.append((dt, e.count, e.key))
+        site = [f for f in e.stack if "markov-process" in f or "mpa_amd" in f]
+        rows.append((dt, e.count, e.key, site[0].split("/")[-1] if site else (e.stack[0] if e.stack else "?")))
 rows.sort(reverse=True)
-for dt, cnt, key in rows[:25]:
-    print("%9.1f us %5d calls  %s" % (dt, cnt, key))
+for dt, cnt, key, site in rows[:45]:
+    print("%9.1f us %5d calls  %-28s %s" % (dt, cnt, key, site[:90]))
