@@ -30,7 +30,8 @@ NUM_POINT, NUM_CLASS = 1024, 40
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 MFMA_F32_PEAK_TFLOPS = 157.3     # dense fp32 MFMA peak (MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32)
 # kernels timed with HIP events for the roofline leg: name -> bound
-TIMED = {"mpa_gemm_f32": "mfma", "mpa_knn_f32": "mfma", "mpa_diffattn_fwd_f32": "hbm", "mpa_diffattn_bwd_f32": "hbm"}
+TIMED = {"mpa_gemm_f32": "mfma", "mpa_gemm_tn_grouped_f32": "mfma", "mpa_knn_f32": "mfma",
+         "mpa_diffattn_fwd_f32": "hbm", "mpa_diffattn_bwd_f32": "hbm"}
 
 
 def synthetic_batch(B, seed, device):
@@ -175,12 +176,20 @@ def main():
             graphed._fwd_bwd()
     kt = ops.kernel_timing_results()
     ops.disable_kernel_timing()
+    pair_us = None
+    if rank == 0:       # what an (empty) HIP event pair itself costs on this stream: the bracket's overhead
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(100)]
+        for e0, e1 in evs:
+            e0.record()
+            e1.record()
+        torch.cuda.synchronize()
+        pair_us = sorted(e0.elapsed_time(e1) * 1e3 for e0, e1 in evs)[50]
 
     if rank == 0:
         clouds = a.batch * world * a.steps
         traffic = {}
         try:        # HBM bytes per launch from the committed rocprofv3 PMC passes (see the file's "how")
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+            with open(os.path.join(ROOT, "profiles", "r01c_pmc_traffic.json")) as fh:
                 traffic = {k: v.get("hbm_bytes_per_launch") for k, v in json.load(fh)["kernels"].items()}
         except (OSError, ValueError, KeyError):
             pass
@@ -202,6 +211,7 @@ def main():
         kernels.sort(key=lambda k: -k["total_ms"])
         roof = dict(kernels[0]) if kernels else None       # the dominant kernel by measured time
         if roof:
+            roof["empty_event_pair_us"] = pair_us     # included in avg_launch_us (not subtracted): frac is a lower bound
             roof["measured"] = ("HIP events around every launch of the kernel, " +
                                 ("inside the timed region" if a.eager else
                                  "eager pass over the same step right after the timed (graph-replayed) region"))

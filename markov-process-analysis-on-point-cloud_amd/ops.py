@@ -510,7 +510,9 @@ def flush_weight_grads():
             ws_bytes += (splits * M * N * 4 + 255) // 256 * 256
     dev = _DW_QUEUE[0][0].device
     ws = _workspace(dev, max(ws_bytes, 4))
-    _launch("mpa_gemm_tn_grouped_f32", arr, n, _p(ws), ws.numel() * 4, _stream())
+    _launch("mpa_gemm_tn_grouped_f32", arr, n, _p(ws), ws.numel() * 4, _stream(),
+            algo_bytes=sum(4 * (q[7] * (q[5] + q[6]) + q[5] * q[6]) for q in _DW_QUEUE),
+            algo_flops=sum(2 * q[5] * q[6] * q[7] for q in _DW_QUEUE))
     _DW_QUEUE.clear()
 
 
