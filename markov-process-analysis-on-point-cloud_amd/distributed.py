@@ -88,6 +88,7 @@ class GradReducer:
         # every parameter is used once per step (true for the cls / part-seg models) and
         # zero_grad() is called every step.
         self.direct = direct
+        self.module = module
         self.params = [p for p in module.parameters() if p.requires_grad]
         self.bucket_bytes = bucket_bytes
         self.buckets = None          # list of dicts: flat, params, pending, handle
@@ -99,14 +100,30 @@ class GradReducer:
     def _build(self):
         live = [p for p in self.params if p.grad is not None]
         live.reverse()               # roughly the order gradients become ready
+        # parameter groups that a module wants back to back in the flat buffers (LocalTrans' k|v
+        # projections are read as one stacked weight): a group is placed whole, in its own order
+        group_of = {}
+        for m in self.module.modules():
+            for grp in getattr(m, "mpa_adjacent_params", lambda: ())():
+                grp = [p for p in grp if p.grad is not None]
+                if len(grp) > 1:
+                    for p in grp:
+                        group_of[p] = grp
+        units, seen = [], set()
+        for p in live:
+            if p in seen:
+                continue
+            unit = group_of.get(p, [p])
+            units.append(unit)
+            seen.update(unit)
         self.buckets = []
         cur, cur_bytes = [], 0
-        for p in live:
-            nbytes = p.numel() * p.element_size()
+        for unit in units:
+            nbytes = sum(p.numel() * p.element_size() for p in unit)
             if cur and cur_bytes + nbytes > self.bucket_bytes:
                 self._make_bucket(cur)
                 cur, cur_bytes = [], 0
-            cur.append(p)
+            cur.extend(unit)
             cur_bytes += nbytes
         if cur:
             self._make_bucket(cur)

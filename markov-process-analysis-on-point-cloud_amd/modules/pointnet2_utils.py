@@ -79,6 +79,11 @@ class LocalTrans(nn.Module):
         self.ffn = Linear(out_c, out_c, bn=False)
         self.tanh = nn.Tanh()
 
+    def mpa_adjacent_params(self):
+        """Parameters the flat buffers should keep back to back (distributed.GradReducer): the key and
+        value projections are applied as one stacked weight (ops.linear_kv)."""
+        return ((self.k.weight, self.v.weight), (self.k.bias, self.v.bias))
+
     def forward(self, features, idx, pos, FPS_idx=None, xyz=False, center=None):
         # `center` (optional, not in the reference signature): index_points(features, FPS_idx) when
         # the caller already has it (LocalMerge gathers it once for both feature streams and the kNN)

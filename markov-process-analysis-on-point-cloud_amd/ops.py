@@ -8,6 +8,7 @@ Function names and argument order follow the reference's modules/pointnet2_utils
 (`cuda=`, `is_group=`) are accepted and ignored.
 """
 import ctypes
+import os
 
 import torch
 
@@ -197,7 +198,7 @@ class GeometryPass:
 
 
 _GEO_STREAMS = {}
-GEOMETRY_SIDE_STREAM = False     # True: side stream (measured: no gain under HIP-graph replay on MI355X, r01)
+GEOMETRY_SIDE_STREAM = os.environ.get("MPA_GEO_SIDE", "0") == "1"   # side stream for the FPS/kNN chain
 
 
 def geometry_pass(xyz, npoints, k):
@@ -601,6 +602,16 @@ def linear(x, weight, bias, bias_grad_is_zero=False):
     return y.view(*lead, weight.shape[0])
 
 
+def _stacked(a, b):
+    """torch.cat((a, b), 0), as a view when b's storage directly follows a's."""
+    if (a.is_contiguous() and b.is_contiguous() and a.shape[1:] == b.shape[1:]
+            and b.data_ptr() == a.data_ptr() + a.numel() * a.element_size()
+            and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()):
+        rows = a.shape[0] + b.shape[0]
+        return a.detach().as_strided((rows,) + tuple(a.shape[1:]), a.stride())
+    return torch.cat((a.detach(), b.detach()), 0)
+
+
 class _LinearKV(torch.autograd.Function):
     """kv[M, 2C] = x [Wk; Wv]^T + [bk; bv]: the key and value projections of LocalTrans' feature
     branch as one GEMM (keys in columns [0,C), values in [C,2C)), without materialising the
@@ -611,8 +622,10 @@ class _LinearKV(torch.autograd.Function):
     def forward(ctx, x, Wk, bk, Wv, bv):
         M, K = x.shape
         C = Wk.shape[0]
-        Wkv = torch.cat((Wk, Wv), 0)
-        bkv = torch.cat((bk, bv), 0)
+        # [Wk; Wv] and [bk; bv] without a copy when the parameters sit back to back in memory
+        # (optim.FlatAdam's flat parameter buffers keep LocalTrans' k|v pairs adjacent)
+        Wkv = _stacked(Wk, Wv)
+        bkv = _stacked(bk, bv)
         kv = torch.empty(M, 2 * C, dtype=torch.float32, device=x.device)
         _gemm(x, K, 0, Wkv, K, 1, bkv, kv, 2 * C, M, 2 * C, K)
         ctx.save_for_backward(x, Wkv)
