@@ -64,9 +64,11 @@ class GraphedTrainStep:
     rank."""
 
     def __init__(self, model, loss_fn, example_batch, optimizer=None, lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
-                 weight_decay=0.0, warmup=2, bucket_bytes=16 << 20):
+                 weight_decay=0.0, warmup=2, bucket_bytes=16 << 20, compute_loss=None):
+        # compute_loss(model, loss_fn, *batch) -> scalar loss; default: loss_fn(model(batch[0]), *batch[1:])
         from .optim import FlatAdam
         self.model, self.loss_fn = model, loss_fn
+        self.compute_loss = compute_loss
         self.static = [t.clone() for t in example_batch]
         self.feeder = FpsStartFeeder()
         self.reducer = GradReducer(model, bucket_bytes=bucket_bytes, direct=True)
@@ -97,7 +99,10 @@ class GraphedTrainStep:
     def _fwd_bwd(self):
         self.feeder.begin_pass()
         self.reducer.zero_grad()
-        loss = self.loss_fn(self.model(self.static[0]), *self.static[1:])
+        if self.compute_loss is not None:
+            loss = self.compute_loss(self.model, self.loss_fn, *self.static)
+        else:
+            loss = self.loss_fn(self.model(self.static[0]), *self.static[1:])
         ops.defer_weight_grads(True)          # dW products are queued during backward ...
         try:
             loss.backward()

@@ -21,14 +21,13 @@ def step():
 for _ in range(3): step()
 torch.cuda.synchronize()
 from torch.profiler import profile, ProfilerActivity
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
     step(); torch.cuda.synchronize()
 rows = []
-for e in prof.key_averages(group_by_stack_n=12):
+for e in prof.key_averages(group_by_input_shape=True):
     dt = getattr(e, "device_time_total", None) or getattr(e, "cuda_time_total", 0)
     if dt > 0 and e.key.startswith("aten::"):
-        site = [f for f in e.stack if "markov-process" in f or "mpa_amd" in f]
-        rows.append((dt, e.count, e.key, site[0].split("/")[-1] if site else (e.stack[0] if e.stack else "?")))
+        rows.append((dt, e.count, e.key, str(e.input_shapes)))
 rows.sort(reverse=True)
-for dt, cnt, key, site in rows[:45]:
-    print("%9.1f us %5d calls  %-28s %s" % (dt, cnt, key, site[:90]))
+for dt, cnt, key, shp in rows[:70]:
+    print("%9.1f us %5d calls  %-22s %s" % (dt, cnt, key, shp[:110]))
