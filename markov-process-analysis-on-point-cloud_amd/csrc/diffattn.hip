@@ -408,69 +408,141 @@ __global__ __launch_bounds__(TPB) void diffattn_bwd_p1_v4_kernel(
 
 // lane = (base row, V channels); rows_per_block = 256 / lanes_per_row; blockIdx.y = cloud, so the
 // cloud's bases are scalar and the per-lane offsets 32-bit (S*K*C < 2^31 checked by the host).
+// Rows with more than P2_LONG entries (hubs: e.g. the kNN of many identical feature rows all
+// returns the same neighbours) are left to a second phase in which the whole workgroup shares one
+// row's entries and combines through LDS; without it one lane group walks thousands of entries
+// while the rest of the chip waits (420 us instead of 20 us per launch in the part-seg decoder).
+constexpr int P2_LONG = 48;
+
 template <int V>
 __global__ __launch_bounds__(TPB) void diffattn_bwd_p2_kernel(
     const float *__restrict__ T, const float *__restrict__ Tv, const uint8_t *__restrict__ argk,
     const int *__restrict__ rowptr, const int *__restrict__ entries, int N, int S, int K, int C, int lanes_per_row,
     float *__restrict__ gk, float *__restrict__ gv, int ldg)
 {
+    __shared__ int long_rows[TPB];
+    __shared__ int n_long;
+    __shared__ float red[2 * V * TPB];
     const int rl = threadIdx.x / lanes_per_row, cl = threadIdx.x % lanes_per_row;
     const int rpb = TPB / lanes_per_row;
     const int b = blockIdx.y;
     const int r = blockIdx.x * rpb + rl;
-    if (r >= N) return;
     const int *rp = rowptr + (size_t)b * (N + 1);
-    const int beg = rp[r], end = rp[r + 1];
     const int *en = entries + (size_t)b * S * K;
     const float *Tb = T + (size_t)b * S * K * C;
     const float *Tvb = Tv + (size_t)b * S * C;
     const uint8_t *ab = argk + (size_t)b * S * C;
-    for (int c = cl * V; c < C; c += lanes_per_row * V) {
-        float ak[V], av[V];
-#pragma unroll
-        for (int u = 0; u < V; ++u) ak[u] = av[u] = 0.f;
-        for (int e0 = beg; e0 < end; e0 += 4) {
-            unsigned ent[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) ent[u] = (unsigned)en[min(e0 + u, end - 1)];
-            if constexpr (V == 4) {
-                float4 t[4];
-                uchar4 am[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    t[u] = *reinterpret_cast<const float4 *>(Tb + (ent[u] * (unsigned)C + (unsigned)c));
-                    am[u] = *reinterpret_cast<const uchar4 *>(ab + ((ent[u] / (unsigned)K) * (unsigned)C + (unsigned)c));
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (e0 + u >= end) break;
-                    ak[0] += t[u].x; ak[1] += t[u].y; ak[2] += t[u].z; ak[3] += t[u].w;
-                    const unsigned s_ = ent[u] / (unsigned)K, j = ent[u] - s_ * (unsigned)K;
-                    if (am[u].x == j || am[u].y == j || am[u].z == j || am[u].w == j) {
-                        const float4 d = *reinterpret_cast<const float4 *>(Tvb + (s_ * (unsigned)C + (unsigned)c));
-                        if (am[u].x == j) av[0] += d.x;
-                        if (am[u].y == j) av[1] += d.y;
-                        if (am[u].z == j) av[2] += d.z;
-                        if (am[u].w == j) av[3] += d.w;
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (e0 + u >= end) break;
-                    const unsigned s_ = ent[u] / (unsigned)K, j = ent[u] - s_ * (unsigned)K;
-                    ak[0] += Tb[ent[u] * (unsigned)C + (unsigned)c];
-                    if (ab[s_ * (unsigned)C + (unsigned)c] == j) av[0] += Tvb[s_ * (unsigned)C + (unsigned)c];
-                }
+    if (threadIdx.x == 0) n_long = 0;
+    __syncthreads();
+
+    // one entry's contribution to this lane's V channels starting at c
+    auto add_entry = [&](unsigned ent, int c, float (&ak)[V], float (&av)[V]) {
+        const unsigned s_ = ent / (unsigned)K, j = ent - s_ * (unsigned)K;
+        if constexpr (V == 4) {
+            const float4 t = *reinterpret_cast<const float4 *>(Tb + (ent * (unsigned)C + (unsigned)c));
+            const uchar4 am = *reinterpret_cast<const uchar4 *>(ab + (s_ * (unsigned)C + (unsigned)c));
+            ak[0] += t.x; ak[1] += t.y; ak[2] += t.z; ak[3] += t.w;
+            if (am.x == j || am.y == j || am.z == j || am.w == j) {
+                const float4 d = *reinterpret_cast<const float4 *>(Tvb + (s_ * (unsigned)C + (unsigned)c));
+                if (am.x == j) av[0] += d.x;
+                if (am.y == j) av[1] += d.y;
+                if (am.z == j) av[2] += d.z;
+                if (am.w == j) av[3] += d.w;
             }
+        } else {
+            ak[0] += Tb[ent * (unsigned)C + (unsigned)c];
+            if (ab[s_ * (unsigned)C + (unsigned)c] == j) av[0] += Tvb[s_ * (unsigned)C + (unsigned)c];
         }
-        float *ok = gk + ((size_t)b * N + r) * ldg + c, *ov = gv + ((size_t)b * N + r) * ldg + c;
+    };
+    auto store_row = [&](int row, int c, const float (&ak)[V], const float (&av)[V]) {
+        float *ok = gk + ((size_t)b * N + row) * ldg + c, *ov = gv + ((size_t)b * N + row) * ldg + c;
         if constexpr (V == 4) {
             *reinterpret_cast<float4 *>(ok) = make_float4(ak[0], ak[1], ak[2], ak[3]);
             *reinterpret_cast<float4 *>(ov) = make_float4(av[0], av[1], av[2], av[3]);
         } else {
             ok[0] = ak[0];
             ov[0] = av[0];
+        }
+    };
+
+    if (r < N) {
+        const int beg = rp[r], end = rp[r + 1];
+        if (end - beg > P2_LONG) {
+            if (cl == 0) long_rows[atomicAdd(&n_long, 1)] = r;
+        } else {
+            for (int c = cl * V; c < C; c += lanes_per_row * V) {
+                float ak[V], av[V];
+#pragma unroll
+                for (int u = 0; u < V; ++u) ak[u] = av[u] = 0.f;
+                for (int e0 = beg; e0 < end; e0 += 4) {
+                    unsigned ent[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) ent[u] = (unsigned)en[min(e0 + u, end - 1)];
+                    if constexpr (V == 4) {
+                        float4 t[4];
+                        uchar4 am[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {                  // four rows of T in flight together
+                            t[u] = *reinterpret_cast<const float4 *>(Tb + (ent[u] * (unsigned)C + (unsigned)c));
+                            am[u] = *reinterpret_cast<const uchar4 *>(ab + ((ent[u] / (unsigned)K) * (unsigned)C + (unsigned)c));
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            if (e0 + u >= end) break;
+                            ak[0] += t[u].x; ak[1] += t[u].y; ak[2] += t[u].z; ak[3] += t[u].w;
+                            const unsigned s_ = ent[u] / (unsigned)K, j = ent[u] - s_ * (unsigned)K;
+                            if (am[u].x == j || am[u].y == j || am[u].z == j || am[u].w == j) {
+                                const float4 d = *reinterpret_cast<const float4 *>(Tvb + (s_ * (unsigned)C + (unsigned)c));
+                                if (am[u].x == j) av[0] += d.x;
+                                if (am[u].y == j) av[1] += d.y;
+                                if (am[u].z == j) av[2] += d.z;
+                                if (am[u].w == j) av[3] += d.w;
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            if (e0 + u >= end) break;
+                            add_entry(ent[u], c, ak, av);
+                        }
+                    }
+                }
+                store_row(r, c, ak, av);
+            }
+        }
+    }
+    __syncthreads();
+    const int nl = n_long;
+    for (int li = 0; li < nl; ++li) {
+        const int row = long_rows[li];
+        const int beg = rp[row], end = rp[row + 1];
+        for (int c0 = 0; c0 < C; c0 += lanes_per_row * V) {
+            const int c = c0 + cl * V;
+            float ak[V], av[V];
+#pragma unroll
+            for (int u = 0; u < V; ++u) ak[u] = av[u] = 0.f;
+            if (c < C)
+                for (int e = beg + rl; e < end; e += rpb) add_entry((unsigned)en[e], c, ak, av);
+#pragma unroll
+            for (int u = 0; u < V; ++u) {
+                red[(u * 2) * TPB + threadIdx.x] = ak[u];
+                red[(u * 2 + 1) * TPB + threadIdx.x] = av[u];
+            }
+            __syncthreads();
+            if (rl == 0 && c < C) {
+#pragma unroll
+                for (int u = 0; u < V; ++u) {
+                    float sk = 0.f, sv = 0.f;
+                    for (int y = 0; y < rpb; ++y) {
+                        sk += red[(u * 2) * TPB + y * lanes_per_row + cl];
+                        sv += red[(u * 2 + 1) * TPB + y * lanes_per_row + cl];
+                    }
+                    ak[u] = sk;
+                    av[u] = sv;
+                }
+                store_row(row, c, ak, av);
+            }
+            __syncthreads();
         }
     }
 }

@@ -37,13 +37,17 @@ def compute_loss(model, crit, x, label, target):
 
 print("building graph ...", flush=True)
 step = GraphedTrainStep(model, crit, (x, label, target), lr=1e-3, compute_loss=compute_loss)
-for _ in range(3):
-    step(x, label, target)
+for i in range(4):
+    l = step(x, label, target)
+    print("warm-up step %d loss %.5f" % (i, float(l.detach())), flush=True)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
+losses = []
 for _ in range(steps):
     loss = step(x, label, target)
+    losses.append(loss.detach().clone())
 torch.cuda.synchronize()
+print("losses:", " ".join("%.4f" % float(l) for l in losses[:: max(1, steps // 16)]), flush=True)
 dt = (time.perf_counter() - t0) / steps
 print("seg fp32 B=%d N=%d: %.2f ms/step, %.1f clouds/s, loss %.4f, peak mem %.1f GB" % (
-    B, N, dt * 1e3, B / dt, float(loss), torch.cuda.max_memory_allocated() / 2**30), flush=True)
+    B, N, dt * 1e3, B / dt, float(loss.detach()), torch.cuda.max_memory_allocated() / 2**30), flush=True)
