@@ -154,6 +154,15 @@ inline int grid_for(long long total)
     return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
 }
 
+// plain kernel instead of hipMemsetAsync: inside a captured HIP graph the clear is then an ordinary
+// kernel node like its neighbours (no memset nodes anywhere on the path)
+__global__ void clear_kernel(float *__restrict__ a, long long na, float *__restrict__ b, long long nb)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < na; i += stride) a[i] = 0.f;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nb; i += stride) b[i] = 0.f;
+}
+
 }  // namespace
 
 extern "C" int mpa_gather_fwd_f32(const float *points, const int64_t *idx, int B, int N, int M, int C, float *out,
@@ -194,8 +203,8 @@ extern "C" int mpa_upsample_mean_fwd_f32(const float *points, const int64_t *knn
     MPA_CLEAR_ERROR();
     if (!points || !knn_idx || !out || !cnt || B <= 0 || S <= 0 || K <= 0 || Nf <= 0 || C <= 0) return MPA_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * Nf * C, st) != hipSuccess) return MPA_EHIP;
-    if (hipMemsetAsync(cnt, 0, sizeof(float) * (size_t)B * Nf, st) != hipSuccess) return MPA_EHIP;
+    hipLaunchKernelGGL(clear_kernel, dim3(grid_for((long long)B * Nf * C)), dim3(TPB), 0, st, out, (long long)B * Nf * C,
+                       cnt, (long long)B * Nf);
     long long total = (long long)B * S * K * C;
     hipLaunchKernelGGL(upsample_scatter_kernel, dim3(grid_for(total)), dim3(TPB), 0, st, points, knn_idx, S, K, Nf, C,
                        total, out, cnt);

@@ -135,19 +135,22 @@ class GradReducer:
                 p.register_post_accumulate_grad_hook(self._hook)
 
     def _make_bucket(self, params):
-        total = sum(p.numel() for p in params)
-        flat = torch.zeros(total, dtype=params[0].dtype, device=params[0].device)
-        b = {"flat": flat, "params": params, "pending": len(params), "views": []}
-        off = 0
+        # every view starts on a 16-byte boundary (a 50-float bias would otherwise push all later
+        # parameters off the float4 paths of the kernels); the pad elements stay zero
+        offs, off = [], 0
         for p in params:
-            v = flat[off:off + p.numel()].view_as(p)
+            offs.append(off)
+            off += (p.numel() + 3) // 4 * 4
+        flat = torch.zeros(off, dtype=params[0].dtype, device=params[0].device)
+        b = {"flat": flat, "params": params, "pending": len(params), "views": [], "offsets": offs}
+        for p, o in zip(params, offs):
+            v = flat[o:o + p.numel()].view_as(p)
             v.copy_(p.grad)
             p.grad = v
             b["views"].append(v)
             if self.direct:
                 p._mpa_grad_buf = v
             self._where[p] = b
-            off += p.numel()
         self.buckets.append(b)
 
     def _hook(self, p):

@@ -21,14 +21,11 @@ class FlatAdam:
         self.groups = []
         for b in reducer.buckets:
             flat_g = b["flat"]
-            flat_p = torch.empty_like(flat_g)
-            off = 0
-            for p in b["params"]:
-                n = p.numel()
-                view = flat_p[off:off + n].view_as(p)
+            flat_p = torch.zeros_like(flat_g)
+            for p, off in zip(b["params"], b["offsets"]):
+                view = flat_p[off:off + p.numel()].view_as(p)
                 view.copy_(p.data)
                 p.data = view
-                off += n
             self.groups.append({"p": flat_p, "g": flat_g, "m": torch.zeros_like(flat_g),
                                 "v": torch.zeros_like(flat_g)})
         self.step_count = torch.zeros(1, dtype=torch.float32, device=reducer.buckets[0]["flat"].device)
