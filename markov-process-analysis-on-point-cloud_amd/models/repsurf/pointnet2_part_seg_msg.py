@@ -39,4 +39,10 @@ class get_loss(nn.Module):
         n_class = pred.size(1)
         one_hot = pred.new_zeros(pred.shape).scatter(1, target.view(-1, 1), 1)
         one_hot = one_hot * (1 - eps) + (1 - one_hot) * eps / (n_class - 1)
-        return -(one_hot * F.log_softmax(pred, dim=1)).sum(dim=1).mean()
+        per_point = -(one_hot * F.log_softmax(pred, dim=1)).sum(dim=1)
+        n = per_point.numel()
+        if n > 4096 and n % 64 == 0:
+            # mean in two stages (<= 64 and n/64 elements): keeps torch off its multi-workgroup
+            # reduction, whose result is not reliable under HIP-graph replay (see _max_over_points)
+            return per_point.view(-1, 64).mean(dim=1).mean()
+        return per_point.mean()

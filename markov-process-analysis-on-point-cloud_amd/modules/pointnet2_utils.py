@@ -184,6 +184,18 @@ class Fuse(nn.Module):
         return tuple(f)
 
 
+def _max_over_points(t):
+    """t.max(dim=1, keepdim=True)[0] for [B,N,C] (reference :846-850), taken in two stages of <= 64
+    points each when N allows.  Same values and the same (first-maximum) gradient routing; the
+    single-stage form makes torch pick its multi-workgroup reduction, whose result was wrong from
+    the second replay of a captured HIP graph on (garbage arg-max indices -> the backward's
+    scatter_ faulted); the staged form never leaves one workgroup per output."""
+    B, N, C = t.shape
+    if N > 64 and N % 64 == 0:
+        return t.view(B, N // 64, 64, C).max(dim=2)[0].max(dim=1, keepdim=True)[0]
+    return t.max(dim=1, keepdim=True)[0]
+
+
 class KeepHighResolutionModulePartSeg(nn.Module):
     """Part-seg encoder-decoder wiring (reference :711-858)."""
 
@@ -246,7 +258,7 @@ class KeepHighResolutionModulePartSeg(nn.Module):
         d0 = self.la1_up(xyz=x0, base_xyz=x0, normal=n0, feature=self.up_conv1(upsample(d1, k1)))[0]
         d0 = self.fuse5(N, f0=d0, f1=e1, f2=e2, f3=e3, f4=e4, **geo)[0]
 
-        glob = torch.cat([t.max(dim=1, keepdim=True)[0] for t in (d0, d1, d2, d3, d4)], dim=2)
+        glob = torch.cat([_max_over_points(t) for t in (d0, d1, d2, d3, d4)], dim=2)
         glob = glob.expand(-1, N, -1)
         lab = self.conv7(label).expand(-1, N, -1)
         final = torch.cat((self.conv5(d0), glob, lab), 2)

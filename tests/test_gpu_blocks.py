@@ -387,3 +387,39 @@ def test_sample_legacy_helper(P):
     idx = P.farthest_point_sample(pts[:, :3].transpose(1, 2).contiguous(), 100)
     ref = torch.gather(pts, 2, idx.unsqueeze(1).expand(-1, 6, -1))
     assert out.shape == (3, 6, 100) and torch.equal(out, ref)
+
+
+# --------------------------------------------------------------------- HIP-graph train step
+def test_graphed_partseg_step_replays_stay_finite():
+    """The captured part-seg step (direct gradients, grouped dW, FlatAdam) replayed several times:
+    regression for torch's multi-workgroup max reduction going wrong from the second replay on
+    (modules/pointnet2_utils._max_over_points) -- losses must stay finite and fall."""
+    import mpa_amd  # noqa: F401
+    from mpa_amd.models.repsurf.pointnet2_part_seg_msg import get_model, get_loss
+    from mpa_amd.runtime import GraphedTrainStep
+    B, N = 2, 2048
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(5)
+    x = (torch.rand(B, 3, N, generator=g) * 2 - 1).to(dev)
+    label = torch.zeros(B, 1, 16)
+    label[:, 0, 3] = 1
+    label = label.to(dev)
+    target = torch.randint(0, 50, (B, N), generator=g).to(dev)
+    torch.manual_seed(0)
+    model = get_model(50).to(dev).train()
+
+    def compute_loss(model, crit, x, label, target):
+        pred, _ = model(x, label)
+        return crit(pred.reshape(-1, 50), target.reshape(-1))
+
+    step = GraphedTrainStep(model, get_loss(), (x, label, target), lr=1e-3, compute_loss=compute_loss)
+    try:
+        losses = []
+        for _ in range(6):
+            losses.append(float(step(x, label, target).detach()))
+            torch.cuda.synchronize()
+            for p in model.parameters():
+                assert p.grad is None or torch.isfinite(p.grad).all()
+        assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    finally:
+        step.close()
