@@ -510,6 +510,113 @@ __global__ void splitk_reduce_grouped_kernel(const GroupedReduceArgs args)
     if (z0 < z1) atomicAdd(q.out + e, (a0 + a1) + (a2 + a3));
 }
 
+// ---- short-K products (K = 64 or 128, whole tiles): the layers of the fine point-set states,
+// M = B*S up to 65536 rows against 64..256 channels.  They are HBM-bound (16 FLOP/B) and, in the
+// general kernel above, latency-bound: one slab means no pipelining inside a workgroup, and its
+// 192 registers + 64 KiB of LDS allow two workgroups per CU.  Here a workgroup stages the whole
+// K extent of its 64 x 64 tile at once (32 KiB per 64 of K), every wave multiplies its own 32 x 32
+// quadrant over all of K (no partial tiles to sum through LDS) and stores from the accumulator;
+// <= 64 registers, so four (K = 64) or two (K = 128) workgroups per CU overlap their load, MFMA
+// and store phases.
+template <bool TB, int NS>
+__global__ __launch_bounds__(NT, 4) void gemm_shortk_kernel(const float *__restrict__ A, int lda,
+                                                            const float *__restrict__ B, int ldb,
+                                                            const float *__restrict__ bias, float *__restrict__ C,
+                                                            int ldc, int M, int N, float *__restrict__ tile_stats)
+{
+    constexpr int LDA = TS, LDB = TS;
+    constexpr int BUF = KS * (LDA + LDB);
+    extern __shared__ float lds[];                 // NS slabs of [k][m] | [k][n], swizzled as in gemm_body
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int tiles_n = N / TS, ntiles = (M / TS) * tiles_n;
+    int id = blockIdx.x;
+    if ((ntiles & 7) == 0) id = (id & 7) * (ntiles >> 3) + (id >> 3);
+    const int tile_m = id / tiles_n;
+    const int m0 = tile_m * TS, n0 = (id % tiles_n) * TS;
+
+    float4 ra[NS][4], rb[NS][4];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = tid + NT * q, r = i >> 4, c = (i & 15) * 4;
+            ra[s][q] = *reinterpret_cast<const float4 *>(A + (size_t)(m0 + r) * lda + s * KS + c);
+            rb[s][q] = *reinterpret_cast<const float4 *>(TB ? B + (size_t)(n0 + r) * ldb + s * KS + c
+                                                            : B + (size_t)(s * KS + r) * ldb + n0 + c);
+        }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        float *As = lds + s * BUF, *Bs = As + KS * LDA;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = tid + NT * q, r = i >> 4, c = (i & 15) * 4;
+            {   // lane holds A[m = r][k = c..c+3] -> As[k][m ^ SWZ(k)]
+                float *d = As + c * LDA + (r ^ SWZ(c));
+                d[0] = ra[s][q].x; d[LDA] = ra[s][q].y; d[2 * LDA] = ra[s][q].z; d[3 * LDA] = ra[s][q].w;
+            }
+            if (TB) {
+                float *d = Bs + c * LDB + (r ^ SWZ(c));
+                d[0] = rb[s][q].x; d[LDB] = rb[s][q].y; d[2 * LDB] = rb[s][q].z; d[3 * LDB] = rb[s][q].w;
+            } else {
+                *reinterpret_cast<float4 *>(Bs + r * LDB + (c ^ SWZ(r))) = rb[s][q];
+            }
+        }
+    }
+    __syncthreads();
+
+    const int mq = (wave & 1) * 32, nq = (wave >> 1) * 32;
+    floatx16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const float *As = lds + s * BUF + half * LDA, *Bs = lds + s * BUF + KS * LDA + half * LDB;
+#pragma unroll 8
+        for (int t = 0; t < KS / 2; ++t) {
+            const int cs = l31 ^ (((t >> 1) & 7) << 2);          // SWZ(2t + half): (k >> 2) & 7 = (t >> 1) & 7
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[2 * t * LDA + mq + cs], Bs[2 * t * LDB + nq + cs], acc, 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue straight from the accumulator: lane = column, 16 rows ((r&3) + 8(r>>2) + 4 half)
+    const int col = n0 + nq + l31;
+    const float bv = bias != nullptr ? bias[col] : 0.f;
+    float csum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float v = acc[r] + bv;
+        acc[r] = v;
+        C[(size_t)(m0 + mq + (r & 3) + 8 * (r >> 2) + 4 * half) * ldc + col] = v;
+        csum += v;
+    }
+    if (tile_stats != nullptr) {
+        // per-column sum and M2 (about the tile mean) over the tile's 64 rows: 16 rows per lane,
+        // the other half-wave's 16, the partner wave's 32 (through LDS: everyone is done reading it)
+        float *st = lds;                             // [4 waves][32] sums, then [4][32] M2 at +128
+        __syncthreads();
+        csum += __shfl_xor(csum, 32, 64);
+        if (half == 0) st[wave * 32 + l31] = csum;
+        __syncthreads();
+        const float tsum = st[wave * 32 + l31] + st[(wave ^ 1) * 32 + l31];
+        const float mu = tsum * (1.0f / TS);
+        float m2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float d = acc[r] - mu;
+            m2 = fmaf(d, d, m2);
+        }
+        m2 += __shfl_xor(m2, 32, 64);
+        if (half == 0) st[128 + wave * 32 + l31] = m2;
+        __syncthreads();
+        if (mq == 0 && half == 0) {
+            float *dst = tile_stats + (size_t)tile_m * 2 * N + col;
+            dst[0] = tsum;
+            dst[N] = st[128 + wave * 32 + l31] + st[128 + (wave ^ 1) * 32 + l31];
+        }
+    }
+}
+
 constexpr size_t gemm_lds_bytes(bool, bool) { return sizeof(float) * 2 * KS * (TS + TS); }   // 64 KiB
 
 template <bool TA, bool TB>
@@ -980,6 +1087,30 @@ extern "C" int mpa_gemm_f32(const float *A, int lda, int transA, const float *B,
     hipStream_t st = (hipStream_t)stream;
     const int vecA = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && (lda % 4 == 0);
     const int vecB = ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && (ldb % 4 == 0);
+
+    // short-K whole-tile products (see gemm_shortk_kernel)
+    static const bool shortk_on = getenv("MPA_GEMM_NO_SHORTK") == nullptr;
+    if (shortk_on && !transA && !accumulate && a_col_sum == nullptr && vecA && vecB && (M % TS) == 0 && (N % TS) == 0 &&
+        (K == KS || K == 2 * KS)) {
+        const dim3 grid((M / TS) * (N / TS));
+        if (K == KS) {
+            if (transB)
+                hipLaunchKernelGGL((gemm_shortk_kernel<true, 1>), grid, dim3(NT), 32768, st, A, lda, B, ldb, bias, C, ldc,
+                                   M, N, tile_stats);
+            else
+                hipLaunchKernelGGL((gemm_shortk_kernel<false, 1>), grid, dim3(NT), 32768, st, A, lda, B, ldb, bias, C, ldc,
+                                   M, N, tile_stats);
+        } else {
+            if (transB)
+                hipLaunchKernelGGL((gemm_shortk_kernel<true, 2>), grid, dim3(NT), 65536, st, A, lda, B, ldb, bias, C, ldc,
+                                   M, N, tile_stats);
+            else
+                hipLaunchKernelGGL((gemm_shortk_kernel<false, 2>), grid, dim3(NT), 65536, st, A, lda, B, ldb, bias, C, ldc,
+                                   M, N, tile_stats);
+        }
+        MPA_LAUNCH_CHECK();
+        return MPA_OK;
+    }
 
     // split K across workgroups when the output alone cannot fill the chip (weight gradients:
     // K = B*S rows; the narrow head layers): aim at ~512 workgroups, >= 256 k per workgroup.
