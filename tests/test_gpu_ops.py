@@ -188,7 +188,8 @@ def test_ops_reject_cpu_tensors(ops):
 @pytest.mark.parametrize("M,N,K,tA,tB", [(300, 64, 64, 0, 1), (1000, 40, 256, 0, 1), (513, 128, 3, 0, 1),
                                          (2048, 512, 1024, 0, 1), (4096, 64, 128, 0, 0), (333, 3, 64, 0, 0),
                                          (64, 64, 8192, 1, 0), (128, 3, 5000, 1, 0), (1024, 2048, 64, 1, 0),
-                                         (70, 50, 30, 1, 1), (65536, 64, 64, 0, 1)])
+                                         (70, 50, 30, 1, 1), (65536, 64, 64, 0, 1),
+                                         (8192, 128, 64, 0, 0), (2048, 256, 128, 0, 1)])      # (+ short-K kernel: NN/NT, K = 64/128)
 def test_gemm_vs_torch(ops, M, N, K, tA, tB):
     g = torch.Generator().manual_seed(M + N + K)
     A = torch.randn((K, M) if tA else (M, K), generator=g).cuda()
