@@ -1202,10 +1202,12 @@ extern "C" int mpa_gemm_tn_grouped_f32(const MpaGemmTnProblem *problems, int cou
             q.lda = in.lda; q.ldb = in.ldb; q.M = in.M; q.N = in.N; q.K = in.K;
             q.tiles = mpa_ceil_div(in.M, TS) * mpa_ceil_div(in.N, TS);
             const size_t mn = (size_t)in.M * in.N;
-            static const int tn_stream = getenv("MPA_TN_STREAM") ? atoi(getenv("MPA_TN_STREAM")) : 1;
+            static const int tn_stream = getenv("MPA_TN_STREAM") ? atoi(getenv("MPA_TN_STREAM")) : 2;
             static const int target_wgs = getenv("MPA_TN_WGS") ? atoi(getenv("MPA_TN_WGS")) : 256;
             static const int min_kchunk = getenv("MPA_TN_KCHUNK") ? atoi(getenv("MPA_TN_KCHUNK")) : 2048;
-            q.stream = tn_stream;
+            // tn_stream: 1 = stream every problem, 0 = LDS-staged, 2 = stream the single-/few-tile
+            // problems (pure HBM streams) and stage the wide ones (MFMA-bound) through LDS
+            q.stream = tn_stream == 2 ? (q.tiles <= 4 ? 1 : 0) : tn_stream;
             q.vec = ((in.lda & 3) == 0 && (reinterpret_cast<uintptr_t>(in.A) & 15) == 0 ? 1 : 0) |
                     ((in.ldb & 3) == 0 && (reinterpret_cast<uintptr_t>(in.B) & 15) == 0 ? 2 : 0);
             int splits = 1;
