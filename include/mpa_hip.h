@@ -75,23 +75,25 @@ int mpa_gather_bwd_f32(const float *grad_out, const int64_t *idx, int B, int N, 
 
 /* ---- LocalTrans, feature branch: the difference-wise attention core,
  * modules/pointnet2_utils.py:548-569 (== repsurface_utils.py:515-535).
- * q [B,S,C]; k and v are row views with leading dimension ldkv floats (k, v = two column
+ * q [B,S,C] row view with leading dimension ldq floats (a column block of stacked projections
+ * is read in place); k and v are row views with leading dimension ldkv floats (k, v = two column
  * blocks of one projected [B,N,ldkv] tensor, or separate tensors with ldkv = C);
  * idx [B,S,K] neighbours into the N base rows.  Per (b,s,c):
  *   e_j = (q - k[idx_j]) / sqrt(C);  a = softmax_j(e);  w_j = a_j - sum_j a_j;
  *   ctx = max_j w_j * v[idx_j]
  * ctx [B,S,C]; argk [B,S,C] uint8 receives the arg-max j (saved for backward). K <= 16. */
-int mpa_diffattn_fwd_f32(const float *q, const float *k, const float *v, int ldkv,
+int mpa_diffattn_fwd_f32(const float *q, int ldq, const float *k, const float *v, int ldkv,
                          const int64_t *idx, int B, int N, int S, int K, int C,
                          float *ctx, uint8_t *argk, void *stream);
-/* backward (closed form): recomputes the softmax; grad_q [B,S,C] and
+/* backward (closed form): recomputes the softmax; grad_q ([B,S,C] row view with
+ * q's leading dimension ldq) and
  * grad_k / grad_v ([B,N,C] row views, leading dimension ldg) are all overwritten -- no clearing
  * by the caller.  With a workspace of mpa_diffattn_bwd_workspace_bytes() the scatter through idx
  * is done without float atomics (inverted neighbour table + per-slot gradients, summed per base
  * row); with workspace == NULL (or too small, or a shape for which the size
  * query returns 0) it falls back to global float atomics after clearing grad_k / grad_v. */
 size_t mpa_diffattn_bwd_workspace_bytes(int B, int N, int S, int K, int C);
-int mpa_diffattn_bwd_f32(const float *q, const float *k, const float *v, int ldkv,
+int mpa_diffattn_bwd_f32(const float *q, int ldq, const float *k, const float *v, int ldkv,
                          const int64_t *idx, const uint8_t *argk, const float *grad_ctx,
                          int B, int N, int S, int K, int C,
                          float *grad_q, float *grad_k, float *grad_v, int ldg,

@@ -32,8 +32,8 @@ SIGNATURES = {
     "mpa_ball_query_f32": [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp],
     "mpa_gather_fwd_f32": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "mpa_gather_bwd_f32": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
-    "mpa_diffattn_fwd_f32": [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp],
-    "mpa_diffattn_bwd_f32": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp,
+    "mpa_diffattn_fwd_f32": [_vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp],
+    "mpa_diffattn_bwd_f32": [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp,
                              ctypes.c_size_t, _vp],
     "mpa_diffattn_bwd_workspace_bytes": [_i, _i, _i, _i, _i],
     "mpa_diffattn_xyz_fwd_f32": [_vp] * 9 + [_i] * 5 + [_vp, _vp, _vp],

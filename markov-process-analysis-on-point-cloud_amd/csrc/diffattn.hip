@@ -46,7 +46,7 @@ __device__ __forceinline__ void softmax_offset(const float *e, int K, float *a, 
 // ------------------------------------------------------------------ feature branch
 template <int K_>
 __global__ __launch_bounds__(TPB) void diffattn_fwd_kernel(const float *__restrict__ q, const float *__restrict__ kk,
-                                                           const float *__restrict__ vv, int ldkv,
+                                                           const float *__restrict__ vv, int ldkv, int ldq,
                                                            const int64_t *__restrict__ idx, int N, int S, int K,
                                                            int C, float alpha, long long total,
                                                            float *__restrict__ ctx, uint8_t *__restrict__ argk)
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(TPB) void diffattn_fwd_kernel(const float *__restri
         int c = (int)(i - p * C);
         int b = (int)(p / S);
         const int64_t *nb = idx + p * k_;
-        const float qv = q[i];
+        const float qv = q[p * ldq + c];
         float e[K_ > 0 ? K_ : KMAX], v[K_ > 0 ? K_ : KMAX], a[K_ > 0 ? K_ : KMAX];
 #pragma unroll
         for (int j = 0; j < (K_ > 0 ? K_ : KMAX); ++j)
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(TPB) void diffattn_fwd_kernel(const float *__restri
 // 16 B per lane (C % 4 == 0, 16-B aligned rows).
 template <int K_>
 __global__ __launch_bounds__(TPB) void diffattn_fwd_v4_kernel(const float *__restrict__ q, const float *__restrict__ kk,
-                                                              const float *__restrict__ vv, int ldkv,
+                                                              const float *__restrict__ vv, int ldkv, int ldq,
                                                               const int64_t *__restrict__ idx, int N, int S, int K,
                                                               int C, float alpha, long long total4,
                                                               float *__restrict__ ctx, uint8_t *__restrict__ argk)
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(TPB) void diffattn_fwd_v4_kernel(const float *__res
         const int c = (int)(i - p * c4n) << 2;
         const int b = (int)(p / S);
         const int64_t *nb = idx + p * k_;
-        const float4 q4 = *reinterpret_cast<const float4 *>(q + p * C + c);
+        const float4 q4 = *reinterpret_cast<const float4 *>(q + p * ldq + c);
         const float qv[4] = {q4.x, q4.y, q4.z, q4.w};
         float4 k4[KK], v4[KK];
 #pragma unroll
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(TPB) void diffattn_fwd_v4_kernel(const float *__res
 
 template <int K_>
 __global__ __launch_bounds__(TPB) void diffattn_bwd_kernel(const float *__restrict__ q, const float *__restrict__ kk,
-                                                           const float *__restrict__ vv, int ldkv,
+                                                           const float *__restrict__ vv, int ldkv, int ldq,
                                                            const int64_t *__restrict__ idx,
                                                            const uint8_t *__restrict__ argk,
                                                            const float *__restrict__ gctx, int N, int S, int K, int C,
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(TPB) void diffattn_bwd_kernel(const float *__restri
         int c = (int)(i - p * C);
         int b = (int)(p / S);
         const int64_t *nb = idx + p * k_;
-        const float qv = q[i];
+        const float qv = q[p * ldq + c];
         const int ks = argk[i];
         const float g = gctx[i];
         float e[K_ > 0 ? K_ : KMAX], a[K_ > 0 ? K_ : KMAX];
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(TPB) void diffattn_bwd_kernel(const float *__restri
                 dq += de;
                 atomicAdd(gk + rows[j] * ldg + c, -alpha * de);
             }
-        gq[i] = alpha * dq;
+        gq[p * ldq + c] = alpha * dq;
         atomicAdd(gv + rstar * ldg + c, g * (astar - o));
     }
 }
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(CSR_TPB) void csr_build_kernel(const int64_t *__res
 
 template <int K_>
 __global__ __launch_bounds__(TPB) void diffattn_bwd_p1_kernel(
-    const float *__restrict__ q, const float *__restrict__ kk, const float *__restrict__ vv, int ldkv,
+    const float *__restrict__ q, const float *__restrict__ kk, const float *__restrict__ vv, int ldkv, int ldq,
     const int64_t *__restrict__ idx, const uint8_t *__restrict__ argk, const float *__restrict__ gctx, int N, int S,
     int K, int C, float alpha, long long total, float *__restrict__ gq, float *__restrict__ T,
     float *__restrict__ Tv)
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(TPB) void diffattn_bwd_p1_kernel(
         int c = (int)(i - p * C);
         int b = (int)(p / S);
         const int64_t *nb = idx + p * k_;
-        const float qv = q[i];
+        const float qv = q[p * ldq + c];
         const int ks = argk[i];
         const float g = gctx[i];
         float e[K_ > 0 ? K_ : KMAX], a[K_ > 0 ? K_ : KMAX];
@@ -328,14 +328,14 @@ __global__ __launch_bounds__(TPB) void diffattn_bwd_p1_kernel(
                 dq += de;
                 Tp[(long long)j * C] = -alpha * de;
             }
-        gq[i] = alpha * dq;
+        gq[p * ldq + c] = alpha * dq;
         Tv[i] = g * (astar - o);
     }
 }
 
 template <int K_>
 __global__ __launch_bounds__(TPB) void diffattn_bwd_p1_v4_kernel(
-    const float *__restrict__ q, const float *__restrict__ kk, const float *__restrict__ vv, int ldkv,
+    const float *__restrict__ q, const float *__restrict__ kk, const float *__restrict__ vv, int ldkv, int ldq,
     const int64_t *__restrict__ idx, const uint8_t *__restrict__ argk, const float *__restrict__ gctx, int N, int S,
     int K, int C, float alpha, long long total4, float *__restrict__ gq, float *__restrict__ T,
     float *__restrict__ Tv)
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(TPB) void diffattn_bwd_p1_v4_kernel(
         const int c = (int)(i - p * c4n) << 2;
         const int b = (int)(p / S);
         const int64_t *nb = idx + p * k_;
-        const float4 q4 = *reinterpret_cast<const float4 *>(q + p * C + c);
+        const float4 q4 = *reinterpret_cast<const float4 *>(q + p * ldq + c);
         const float4 g4 = *reinterpret_cast<const float4 *>(gctx + p * C + c);
         const uchar4 ks4 = *reinterpret_cast<const uchar4 *>(argk + p * C + c);
         const float qv[4] = {q4.x, q4.y, q4.z, q4.w}, gv_[4] = {g4.x, g4.y, g4.z, g4.w};
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(TPB) void diffattn_bwd_p1_v4_kernel(
         for (int j = 0; j < KK; ++j)
             if (j < k_)
                 *reinterpret_cast<float4 *>(Tp + (long long)j * C) = make_float4(de[j][0], de[j][1], de[j][2], de[j][3]);
-        *reinterpret_cast<float4 *>(gq + p * C + c) = make_float4(dq4[0], dq4[1], dq4[2], dq4[3]);
+        *reinterpret_cast<float4 *>(gq + p * ldq + c) = make_float4(dq4[0], dq4[1], dq4[2], dq4[3]);
         *reinterpret_cast<float4 *>(Tv + p * C + c) = make_float4(dv4[0], dv4[1], dv4[2], dv4[3]);
     }
 }
@@ -690,28 +690,30 @@ inline int grid_for(long long total)
 
 }  // namespace
 
-extern "C" int mpa_diffattn_fwd_f32(const float *q, const float *k, const float *v, int ldkv, const int64_t *idx,
-                                    int B, int N, int S, int K, int C, float *ctx, uint8_t *argk, void *stream)
+extern "C" int mpa_diffattn_fwd_f32(const float *q, int ldq, const float *k, const float *v, int ldkv,
+                                    const int64_t *idx, int B, int N, int S, int K, int C, float *ctx, uint8_t *argk,
+                                    void *stream)
 {
     MPA_CLEAR_ERROR();
-    if (!q || !k || !v || !idx || !ctx || !argk || B <= 0 || N <= 0 || S <= 0 || K <= 0 || C <= 0 || ldkv < C)
+    if (!q || !k || !v || !idx || !ctx || !argk || B <= 0 || N <= 0 || S <= 0 || K <= 0 || C <= 0 || ldkv < C ||
+        ldq < C)
         return MPA_EINVAL;
     if (K > KMAX) return MPA_EUNSUPPORTED;
     long long total = (long long)B * S * C;
     float alpha = 1.0f / sqrtf((float)C);
     hipStream_t st = (hipStream_t)stream;
     static const bool scalar_only = getenv("MPA_DIFFATTN_SCALAR") != nullptr;
-    const bool vec4 = !scalar_only && (C & 3) == 0 && (ldkv & 3) == 0 &&
+    const bool vec4 = !scalar_only && (C & 3) == 0 && (ldkv & 3) == 0 && (ldq & 3) == 0 &&
                       ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)ctx | (uintptr_t)argk)) & 15) == 0;
     if (vec4 && K == 8)
-        hipLaunchKernelGGL(diffattn_fwd_v4_kernel<8>, dim3(grid_for(total / 4)), dim3(TPB), 0, st, q, k, v, ldkv, idx, N,
-                           S, K, C, alpha, total / 4, ctx, argk);
+        hipLaunchKernelGGL(diffattn_fwd_v4_kernel<8>, dim3(grid_for(total / 4)), dim3(TPB), 0, st, q, k, v, ldkv, ldq, idx,
+                           N, S, K, C, alpha, total / 4, ctx, argk);
     else if (K == 8)
-        hipLaunchKernelGGL(diffattn_fwd_kernel<8>, dim3(grid_for(total)), dim3(TPB), 0, st, q, k, v, ldkv, idx, N, S, K,
-                           C, alpha, total, ctx, argk);
+        hipLaunchKernelGGL(diffattn_fwd_kernel<8>, dim3(grid_for(total)), dim3(TPB), 0, st, q, k, v, ldkv, ldq, idx, N, S,
+                           K, C, alpha, total, ctx, argk);
     else
-        hipLaunchKernelGGL(diffattn_fwd_kernel<0>, dim3(grid_for(total)), dim3(TPB), 0, st, q, k, v, ldkv, idx, N, S, K,
-                           C, alpha, total, ctx, argk);
+        hipLaunchKernelGGL(diffattn_fwd_kernel<0>, dim3(grid_for(total)), dim3(TPB), 0, st, q, k, v, ldkv, ldq, idx, N, S,
+                           K, C, alpha, total, ctx, argk);
     MPA_LAUNCH_CHECK();
     return MPA_OK;
 }
@@ -742,14 +744,14 @@ extern "C" size_t mpa_diffattn_bwd_workspace_bytes(int B, int N, int S, int K, i
     return bwd_workspace(B, N, S, K, C).total;
 }
 
-extern "C" int mpa_diffattn_bwd_f32(const float *q, const float *k, const float *v, int ldkv, const int64_t *idx,
-                                    const uint8_t *argk, const float *grad_ctx, int B, int N, int S, int K, int C,
-                                    float *grad_q, float *grad_k, float *grad_v, int ldg, void *workspace,
+extern "C" int mpa_diffattn_bwd_f32(const float *q, int ldq, const float *k, const float *v, int ldkv,
+                                    const int64_t *idx, const uint8_t *argk, const float *grad_ctx, int B, int N, int S,
+                                    int K, int C, float *grad_q, float *grad_k, float *grad_v, int ldg, void *workspace,
                                     size_t workspace_bytes, void *stream)
 {
     MPA_CLEAR_ERROR();
     if (!q || !k || !v || !idx || !argk || !grad_ctx || !grad_q || !grad_k || !grad_v || B <= 0 || N <= 0 || S <= 0 ||
-        K <= 0 || C <= 0 || ldkv < C || ldg < C)
+        K <= 0 || C <= 0 || ldkv < C || ldg < C || ldq < C)
         return MPA_EINVAL;
     if (K > KMAX) return MPA_EUNSUPPORTED;
     long long total = (long long)B * S * C;
@@ -773,17 +775,17 @@ extern "C" int mpa_diffattn_bwd_f32(const float *q, const float *k, const float 
         hipLaunchKernelGGL(csr_build_kernel, dim3(mpa_ceil_div(N, range), B), dim3(CSR_TPB),
                            (size_t)2 * range * sizeof(int), st, idx, N, S * K, range, rowptr, entries);
         static const bool scalar_only = getenv("MPA_DIFFATTN_SCALAR") != nullptr;
-        const bool p1v4 = !scalar_only && (C & 3) == 0 && (ldkv & 3) == 0 &&
+        const bool p1v4 = !scalar_only && (C & 3) == 0 && (ldkv & 3) == 0 && (ldq & 3) == 0 &&
                           ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)grad_ctx | (uintptr_t)grad_q |
                              (uintptr_t)argk)) & 15) == 0;
         if (p1v4 && K == 8)
             hipLaunchKernelGGL(diffattn_bwd_p1_v4_kernel<8>, dim3(grid_for(total / 4)), dim3(TPB), 0, st, q, k, v, ldkv,
-                               idx, argk, grad_ctx, N, S, K, C, alpha, total / 4, grad_q, T, Tv);
+                               ldq, idx, argk, grad_ctx, N, S, K, C, alpha, total / 4, grad_q, T, Tv);
         else if (K == 8)
-            hipLaunchKernelGGL(diffattn_bwd_p1_kernel<8>, dim3(grid_for(total)), dim3(TPB), 0, st, q, k, v, ldkv, idx,
+            hipLaunchKernelGGL(diffattn_bwd_p1_kernel<8>, dim3(grid_for(total)), dim3(TPB), 0, st, q, k, v, ldkv, ldq, idx,
                                argk, grad_ctx, N, S, K, C, alpha, total, grad_q, T, Tv);
         else
-            hipLaunchKernelGGL(diffattn_bwd_p1_kernel<0>, dim3(grid_for(total)), dim3(TPB), 0, st, q, k, v, ldkv, idx,
+            hipLaunchKernelGGL(diffattn_bwd_p1_kernel<0>, dim3(grid_for(total)), dim3(TPB), 0, st, q, k, v, ldkv, ldq, idx,
                                argk, grad_ctx, N, S, K, C, alpha, total, grad_q, T, Tv);
         const bool v4 = (C & 3) == 0 && (ldg & 3) == 0 && ((((uintptr_t)grad_k | (uintptr_t)grad_v)) & 15) == 0;
         const int per = v4 ? C / 4 : C;
@@ -806,10 +808,10 @@ extern "C" int mpa_diffattn_bwd_f32(const float *q, const float *k, const float 
         return MPA_EHIP;
     }
     if (K == 8)
-        hipLaunchKernelGGL(diffattn_bwd_kernel<8>, dim3(grid_for(total)), dim3(TPB), 0, st, q, k, v, ldkv, idx, argk,
+        hipLaunchKernelGGL(diffattn_bwd_kernel<8>, dim3(grid_for(total)), dim3(TPB), 0, st, q, k, v, ldkv, ldq, idx, argk,
                            grad_ctx, N, S, K, C, alpha, total, grad_q, grad_k, grad_v, ldg);
     else
-        hipLaunchKernelGGL(diffattn_bwd_kernel<0>, dim3(grid_for(total)), dim3(TPB), 0, st, q, k, v, ldkv, idx, argk,
+        hipLaunchKernelGGL(diffattn_bwd_kernel<0>, dim3(grid_for(total)), dim3(TPB), 0, st, q, k, v, ldkv, ldq, idx, argk,
                            grad_ctx, N, S, K, C, alpha, total, grad_q, grad_k, grad_v, ldg);
     MPA_LAUNCH_CHECK();
     return MPA_OK;

@@ -107,8 +107,9 @@ class GradReducer:
             for grp in getattr(m, "mpa_adjacent_params", lambda: ())():
                 grp = [p for p in grp if p.grad is not None]
                 if len(grp) > 1:
-                    for p in grp:
-                        group_of[p] = grp
+                    for p in grp:               # a parameter follows the largest group that names it
+                        if p not in group_of or len(group_of[p]) < len(grp):
+                            group_of[p] = grp
         units, seen = [], set()
         for p in live:
             if p in seen:

@@ -91,7 +91,6 @@ class LocalTrans(nn.Module):
             raise NotImplementedError("usetanh=True is dead code in the reference models (always False)")
         if center is None:
             center = index_points(features, FPS_idx) if FPS_idx is not None else features
-        residual = self.conv_res(center) if self.residual else center
         if xyz:
             context = ops.diffattn_xyz(features, center, idx, self.q.weight, self.q.bias, self.k.weight,
                                        self.k.bias, self.v.weight, self.v.bias)
@@ -100,7 +99,32 @@ class LocalTrans(nn.Module):
             q = ops.linear(center, self.q.weight, self.q.bias, bias_grad_is_zero=True)
             kv = ops.linear_kv(features, self.k, self.v)
             context = ops.diffattn(q, kv, idx)
+        return self.finish(context, center)
+
+    def finish(self, context, center):
+        """out = res + Linear_ffn(context), res = conv_res(centre) if `residual` else the centre."""
+        residual = self.conv_res(center) if self.residual else center
         return self.ffn.fused(context, residual)
+
+
+def stacked_param_groups(t1, t2):
+    """The parameter groups local_trans_pair reads as stacked weights (kept back to back in the flat
+    parameter buffers by distributed.GradReducer / optim.FlatAdam)."""
+    return ((t1.k.weight, t1.v.weight, t2.k.weight, t2.v.weight), (t1.k.bias, t1.v.bias, t2.k.bias, t2.v.bias),
+            (t1.q.weight, t2.q.weight), (t1.q.bias, t2.q.bias))
+
+
+def local_trans_pair(t1, t2, features, idx1, idx2, center):
+    """t1(features, idx1), t2(features, idx2) for two feature-branch LocalTrans blocks that share
+    their base rows and centres (LocalMerge's two feature streams): the four key/value projections
+    are one GEMM over the base rows, the two query projections one GEMM over the centres, and the
+    attention backward hands each stacked projection a single gradient."""
+    if t1.usetanh or t2.usetanh:
+        raise NotImplementedError("usetanh=True is dead code in the reference models (always False)")
+    qq = ops.linear_stack(center, (t1.q, t2.q), (True, True))
+    kvkv = ops.linear_stack(features, (t1.k, t1.v, t2.k, t2.v), (True, False, True, False))
+    c1, c2 = ops.diffattn_pair(qq, kvkv, idx1, idx2)
+    return t1.finish(c1, center), t2.finish(c2, center)
 
 
 class LocalMerge(nn.Module):
@@ -118,6 +142,9 @@ class LocalMerge(nn.Module):
         self.feature_Trans1 = LocalTrans(in_channels, out_channels, knn, usetanh=usetanh, residual=residual)
         self.feature_Trans2 = LocalTrans(in_channels, out_channels, knn, usetanh=usetanh, residual=residual)
 
+    def mpa_adjacent_params(self):
+        return stacked_param_groups(self.feature_Trans1, self.feature_Trans2)
+
     def forward(self, xyz, base_xyz, normal=None, feature=None, FPS_idx=None, xyz_flag=True):
         dist, idx = knn_point(self.knn, base_xyz, xyz)
         if feature is None:
@@ -126,8 +153,7 @@ class LocalMerge(nn.Module):
             fs = feature if FPS_idx is None else index_points(feature, FPS_idx)
             _, idx_feature = knn_point(self.knn, feature, fs)
             xyz_f = self.xyz_Trans(features=base_xyz, idx=idx, pos=base_xyz, FPS_idx=FPS_idx, xyz=True)
-            f1 = self.feature_Trans1(features=feature, idx=idx, pos=base_xyz, FPS_idx=FPS_idx, center=fs)
-            f2 = self.feature_Trans2(features=feature, idx=idx_feature, pos=base_xyz, FPS_idx=FPS_idx, center=fs)
+            f1, f2 = local_trans_pair(self.feature_Trans1, self.feature_Trans2, feature, idx, idx_feature, fs)
             merge_features = self.fc2(torch.cat((xyz_f, f1, f2), dim=2))
         if FPS_idx is not None:
             normal = index_points(normal, FPS_idx)

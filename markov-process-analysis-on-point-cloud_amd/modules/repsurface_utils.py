@@ -15,7 +15,7 @@ import torch.nn.functional as F
 from .. import ops
 from ..ops import (farthest_point_sample, index_points, knn_point, query_ball_point, query_knn_point,  # noqa: F401
                    sample, square_distance)
-from .pointnet2_utils import Linear, LocalTrans
+from .pointnet2_utils import Linear, LocalTrans, local_trans_pair, stacked_param_groups
 
 
 def sample_and_group(npoint, radius, nsample, center, normal, feature, return_normal=True, return_polar=False,
@@ -100,6 +100,9 @@ class LocalMerge(nn.Module):
         self.feature_Trans = LocalTrans(in_channels, out_channels, knn, usetanh=usetanh, residual=residual)
         self.feature_Trans2 = LocalTrans(in_channels, out_channels, knn, usetanh=usetanh, residual=residual)
 
+    def mpa_adjacent_params(self):
+        return stacked_param_groups(self.feature_Trans, self.feature_Trans2)
+
     def forward(self, xyz, base_xyz, normal=None, feature=None, FPS_idx=None, xyz_flag=True, geometry=None):
         # `geometry` (optional, not in the reference signature): this level's precomputed
         # (dist, idx) of knn_point(self.knn, base_xyz, xyz) from ops.geometry_pass
@@ -109,8 +112,7 @@ class LocalMerge(nn.Module):
         else:
             fs = feature if FPS_idx is None else index_points(feature, FPS_idx)
             _, idx_feature = knn_point(self.knn, feature, fs)
-            f1 = self.feature_Trans(features=feature, idx=idx, pos=base_xyz, FPS_idx=FPS_idx, center=fs)
-            f2 = self.feature_Trans2(features=feature, idx=idx_feature, pos=base_xyz, FPS_idx=FPS_idx, center=fs)
+            f1, f2 = local_trans_pair(self.feature_Trans, self.feature_Trans2, feature, idx, idx_feature, fs)
             merge_features = self.fc2(torch.cat((f1, f2), dim=2))
         return merge_features, normal, idx, dist
 

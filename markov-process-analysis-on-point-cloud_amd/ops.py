@@ -293,7 +293,7 @@ class _DiffAttn(torch.autograd.Function):
         argk = torch.empty(B, S, C, dtype=torch.uint8, device=q.device)
         k = kv
         v = kv[:, :, C:]
-        _launch("mpa_diffattn_fwd_f32", _p(q), _p(k), _vp(v.data_ptr()), 2 * C, _p(idx), B, N, S, K, C, _p(out),
+        _launch("mpa_diffattn_fwd_f32", _p(q), C, _p(k), _vp(v.data_ptr()), 2 * C, _p(idx), B, N, S, K, C, _p(out),
                 _p(argk), _stream(), algo_bytes=B * S * (4 * (2 * C + 2 * K * C) + 8 * K + C))
         ctx.save_for_backward(q, kv, idx, argk)
         return out
@@ -310,7 +310,7 @@ class _DiffAttn(torch.autograd.Function):
         # per-slot gradients + inverted neighbour table: the atomic-free backward's scratch
         need = int(lib.mpa_diffattn_bwd_workspace_bytes(B, N, S, K, C))
         ws = torch.empty(need, dtype=torch.uint8, device=q.device) if need else None
-        _launch("mpa_diffattn_bwd_f32", _p(q), _p(kv), _vp(kv.data_ptr() + 4 * C), 2 * C, _p(idx), _p(argk), _p(grad),
+        _launch("mpa_diffattn_bwd_f32", _p(q), C, _p(kv), _vp(kv.data_ptr() + 4 * C), 2 * C, _p(idx), _p(argk), _p(grad),
                 B, N, S, K, C, _p(gq), _p(gkv), _vp(gkv.data_ptr() + 4 * C), 2 * C, _p(ws), 0 if ws is None else ws.numel(), _stream(),
                 algo_bytes=B * S * (4 * (3 * C + 2 * K * C + C) + 8 * K + C))
         return gq, gkv, None
@@ -322,6 +322,56 @@ def diffattn(q, kv, idx):
     idx [B,S,K] -> ctx [B,S,C]."""
     _dev(q, kv, idx)
     return _DiffAttn.apply(_f32(q), _f32(kv), _i64(idx))
+
+
+class _DiffAttnPair(torch.autograd.Function):
+    """Two difference-wise attentions over the same base rows whose projections were computed
+    stacked: qq [B,S,2C] = q1|q2, kvkv [B,N,4C] = k1|v1|k2|v2 (LocalMerge's two feature streams).
+    Each stream reads its column blocks in place; backward writes both streams' gradients into one
+    [B,S,2C] / [B,N,4C] pair, so the stacked projections get ONE gradient each (no additions)."""
+
+    @staticmethod
+    def forward(ctx, qq, kvkv, idx1, idx2):
+        B, S, C2 = qq.shape
+        C = C2 // 2
+        N = kvkv.shape[1]
+        K = idx1.shape[2]
+        outs, argks = [], []
+        for s_, idx in enumerate((idx1, idx2)):
+            out = torch.empty(B, S, C, dtype=torch.float32, device=qq.device)
+            argk = torch.empty(B, S, C, dtype=torch.uint8, device=qq.device)
+            _launch("mpa_diffattn_fwd_f32", _vp(qq.data_ptr() + 4 * C * s_), 2 * C, _vp(kvkv.data_ptr() + 8 * C * s_),
+                    _vp(kvkv.data_ptr() + 8 * C * s_ + 4 * C), 4 * C, _p(idx), B, N, S, K, C, _p(out), _p(argk),
+                    _stream(), algo_bytes=B * S * (4 * (2 * C + 2 * K * C) + 8 * K + C))
+            outs.append(out)
+            argks.append(argk)
+        ctx.save_for_backward(qq, kvkv, idx1, idx2, *argks)
+        return outs[0], outs[1]
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        qq, kvkv, idx1, idx2, a1, a2 = ctx.saved_tensors
+        B, S, C2 = qq.shape
+        C = C2 // 2
+        N = kvkv.shape[1]
+        K = idx1.shape[2]
+        gqq = torch.empty_like(qq)
+        gkvkv = torch.empty_like(kvkv)          # every column block fully written by its stream
+        need = int(lib.mpa_diffattn_bwd_workspace_bytes(B, N, S, K, C))
+        for s_, (idx, argk, g) in enumerate(((idx1, a1, g1), (idx2, a2, g2))):
+            ws = torch.empty(need, dtype=torch.uint8, device=qq.device) if need else None
+            _launch("mpa_diffattn_bwd_f32", _vp(qq.data_ptr() + 4 * C * s_), 2 * C, _vp(kvkv.data_ptr() + 8 * C * s_),
+                    _vp(kvkv.data_ptr() + 8 * C * s_ + 4 * C), 4 * C, _p(idx), _p(argk), _p(g.contiguous()), B, N, S, K,
+                    C, _vp(gqq.data_ptr() + 4 * C * s_), _vp(gkvkv.data_ptr() + 8 * C * s_),
+                    _vp(gkvkv.data_ptr() + 8 * C * s_ + 4 * C), 4 * C, _p(ws), 0 if ws is None else ws.numel(), _stream(),
+                    algo_bytes=B * S * (4 * (3 * C + 2 * K * C + C) + 8 * K + C))
+        return gqq, gkvkv, None, None
+
+
+def diffattn_pair(qq, kvkv, idx1, idx2):
+    """(ctx1, ctx2) of two difference-wise attentions on stacked projections (see _DiffAttnPair)."""
+    _dev(qq, kvkv, idx1, idx2)
+    return _DiffAttnPair.apply(_f32(qq), _f32(kvkv), _i64(idx1), _i64(idx2))
 
 
 class _DiffAttnXYZ(torch.autograd.Function):
@@ -663,6 +713,76 @@ def linear_kv(x, k_lin, v_lin):
     lead = x.shape[:-1]
     kv = _LinearKV.apply(_f32(x).reshape(-1, x.shape[-1]), k_lin.weight, k_lin.bias, v_lin.weight, v_lin.bias)
     return kv.view(*lead, kv.shape[-1])
+
+
+def _stacked_all(ts):
+    """torch.cat(ts, 0) as a view when the tensors sit back to back in one storage."""
+    out = ts[0]
+    for t in ts[1:]:
+        nxt = _stacked(out, t)
+        if nxt.data_ptr() != out.data_ptr():             # not adjacent: one real concatenation
+            return torch.cat([x.detach() for x in ts], 0)
+        out = nxt
+    return out.detach()
+
+
+class _LinearStack(torch.autograd.Function):
+    """y[M, sum N_i] = x [W_0; W_1; ...]^T + [b_0; b_1; ...]: several nn.Linear applied to the same
+    rows as ONE GEMM (LocalMerge: q1|q2 on the centres, k1|v1|k2|v2 on the base rows); backward is one
+    dX GEMM on the stacked weight and one grouped weight-gradient problem per layer.  zero_bias[i]:
+    the caller knows that bias's gradient vanishes identically (q and k projections, see _Linear)."""
+
+    @staticmethod
+    def forward(ctx, x, zero_bias, *wb):
+        Ws, bs = wb[0::2], wb[1::2]
+        M, K = x.shape
+        Wst, bst = _stacked_all(Ws), _stacked_all(bs)
+        Nt = Wst.shape[0]
+        y = torch.empty(M, Nt, dtype=torch.float32, device=x.device)
+        _gemm(x, K, 0, Wst, K, 1, bst, y, Nt, M, Nt, K)
+        ctx.save_for_backward(x, Wst)
+        ctx.sizes = [w.shape[0] for w in Ws]
+        ctx.zero_bias = tuple(zero_bias)
+        ctx.direct = [(_direct(w), _direct(b)) for w, b in zip(Ws, bs)]
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, Wst = ctx.saved_tensors
+        M, K = x.shape
+        Nt = Wst.shape[0]
+        dev = x.device
+        gy, ldg = _rows_ld(gy)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty(M, K, dtype=torch.float32, device=dev)
+            _gemm(gy, ldg, 0, Wst, K, 0, None, gx, K, M, K, Nt)
+        grads = []
+        off = 0
+        for n_i, zb, (dW, db) in zip(ctx.sizes, ctx.zero_bias, ctx.direct):
+            blk = gy[:, off:off + n_i]
+            gW = dW if dW is not None else torch.empty(n_i, K, dtype=torch.float32, device=dev)
+            if zb:
+                _weight_grad(blk, ldg, x, K, gW, n_i, K, M, direct=dW is not None)
+                gb = None if db is not None else _zeros_like_cached(dev, n_i)
+            else:
+                gb_buf = db if db is not None else torch.zeros(n_i, dtype=torch.float32, device=dev)
+                _weight_grad(blk, ldg, x, K, gW, n_i, K, M, a_col_sum=gb_buf, direct=dW is not None and db is not None)
+                gb = None if db is not None else gb_buf
+            grads += [None if dW is not None else gW, gb]
+            off += n_i
+        return (gx, None) + tuple(grads)
+
+
+def linear_stack(x, layers, zero_bias):
+    """[.., sum N_i] = the nn.Linear `layers` applied to x side by side (see _LinearStack)."""
+    _dev(x, layers[0].weight)
+    lead = x.shape[:-1]
+    wb = []
+    for l in layers:
+        wb += [l.weight, l.bias]
+    y = _LinearStack.apply(_f32(x).reshape(-1, x.shape[-1]), tuple(zero_bias), *wb)
+    return y.view(*lead, y.shape[-1])
 
 
 _BN_REPLICAS = 8

@@ -423,3 +423,27 @@ def test_graphed_partseg_step_replays_stay_finite():
         assert all(np.isfinite(losses)) and losses[-1] < losses[0]
     finally:
         step.close()
+
+
+def test_flat_buffers_keep_stacked_projections_adjacent(RS):
+    """After GradReducer + FlatAdam have moved the parameters into the flat buffers, the k|v|k|v and
+    q|q groups of every LocalMerge are read in place (views, no concatenation) and equal torch.cat."""
+    import mpa_amd  # noqa: F401
+    from mpa_amd import ops
+    from mpa_amd.distributed import GradReducer
+    from mpa_amd.optim import FlatAdam
+    torch.manual_seed(0)
+    la = RS.LocalMerge(64, 64, 8, residual=False).cuda().train()
+    xyz = torch.rand(2, 128, 3, device="cuda")
+    feat = torch.randn(2, 128, 64, device="cuda")
+    red = GradReducer(la, direct=True)
+    red.overlap = False
+    red.zero_grad()
+    la(xyz=xyz[:, :64].contiguous(), base_xyz=xyz, feature=feat, FPS_idx=torch.arange(64, device="cuda").repeat(2, 1))[0].sum().backward()
+    red.all_reduce()
+    FlatAdam(red, 1e-3)
+    t1, t2 = la.feature_Trans, la.feature_Trans2
+    for group in ((t1.k.weight, t1.v.weight, t2.k.weight, t2.v.weight), (t1.q.bias, t2.q.bias)):
+        st = ops._stacked_all(group)
+        assert st.data_ptr() == group[0].data_ptr(), "stacked parameters are not adjacent in the flat buffer"
+        assert torch.equal(st, torch.cat([g.detach() for g in group], 0))
