@@ -30,8 +30,10 @@ NUM_POINT, NUM_CLASS = 1024, 40
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 MFMA_F32_PEAK_TFLOPS = 157.3     # dense fp32 MFMA peak (MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32)
 # kernels timed with HIP events for the roofline leg: name -> bound
-TIMED = {"mpa_gemm_f32": "mfma", "mpa_gemm_tn_grouped_f32": "mfma", "mpa_knn_f32": "mfma",
-         "mpa_diffattn_fwd_f32": "hbm", "mpa_diffattn_bwd_f32": "hbm"}
+# (mpa_gemm_f32 launches are priced by the device kernel they pick: the 64x64-tile kernel against the
+#  MFMA peak, the short-K kernel of the K <= 128 layers -- 16 FLOP/B -- against HBM)
+TIMED = {"mpa_gemm_f32/tiled": "mfma", "mpa_gemm_f32/shortk": "hbm", "mpa_gemm_tn_grouped_f32": "mfma",
+         "mpa_knn_f32": "mfma", "mpa_diffattn_fwd_f32": "hbm", "mpa_diffattn_bwd_f32": "hbm"}
 
 
 def synthetic_batch(B, seed, device):

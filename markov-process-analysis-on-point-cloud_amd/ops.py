@@ -50,9 +50,15 @@ def kernel_timing_results():
     return out
 
 
-def _launch(name, *args, algo_bytes=0, algo_flops=0, tag=None):
+def _launch(name, *args, algo_bytes=0, algo_flops=0, tag=None, variant=None):
+    # variant: which device kernel the entry point will pick ("mpa_gemm_f32/shortk"), so that the
+    # roofline leg can price HBM-bound and MFMA-bound launches of one entry point separately
     fn = getattr(lib, name)
-    recs = _TIMERS.get(name) if _TIMERS is not None else None
+    recs = None
+    if _TIMERS is not None:
+        recs = _TIMERS.get(name + "/" + variant) if variant else None
+        if recs is None:
+            recs = _TIMERS.get(name)
     if recs is None:
         check(fn(*args), name)
         return
@@ -499,9 +505,13 @@ def _gemm(A, lda, tA, Bm, ldb, tB, bias, C, ldc, M, N, K, accumulate=0, tile_sta
         if splits > 1:
             ws = _workspace(C.device, splits * M * N * 4)
             ws_bytes = ws.numel() * 4
+    # (mirrors the dispatch of mpa_gemm_f32: whole 64x64 tiles with K = 64 or 128 go to gemm_shortk_kernel)
+    shortk = (not tA and not accumulate and a_col_sum is None and M % 64 == 0 and N % 64 == 0 and K in (64, 128)
+              and lda % 4 == 0 and ldb % 4 == 0 and A.data_ptr() % 16 == 0 and Bm.data_ptr() % 16 == 0)
     _launch("mpa_gemm_f32", _p(A), lda, tA, _p(Bm), ldb, tB, _p(bias), _p(C), ldc, M, N, K, accumulate,
             _p(tile_stats), _p(a_col_sum), _p(ws), ws_bytes, _stream(), algo_bytes=4 * (M * K + N * K + M * N),
-            algo_flops=2 * M * N * K, tag=(M, N, K, tA, tB, tile_stats is not None))
+            algo_flops=2 * M * N * K, tag=(M, N, K, tA, tB, tile_stats is not None),
+            variant="shortk" if shortk else "tiled")
 
 
 _ZEROS = {}

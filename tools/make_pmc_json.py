@@ -8,7 +8,8 @@ import json
 import sys
 
 ENTRY = {          # C-ABI entry point -> (main kernel prefix, helper kernel prefixes)
-    "mpa_gemm_f32": ("gemm_kernel<", ["splitk_reduce_kernel"]),
+    "mpa_gemm_f32/tiled": ("gemm_kernel<", ["splitk_reduce_kernel"]),
+    "mpa_gemm_f32/shortk": ("gemm_shortk_kernel<", []),
     "mpa_gemm_tn_grouped_f32": ("gemm_tn_grouped_kernel", ["splitk_reduce_grouped_kernel"]),
     "mpa_knn_f32": ("knn_mfma_kernel<", []),
     "mpa_diffattn_fwd_f32": ("diffattn_fwd", []),
