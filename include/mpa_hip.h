@@ -60,6 +60,17 @@ int mpa_square_distance_f32(const float *src, const float *dst, int B, int S, in
 int mpa_knn_f32(const float *base, const float *query, int B, int N, int S, int C, int K,
                 float *out_dist, int64_t *out_idx, void *stream);
 
+/* FPS of one point-set state and the xyz-space (C = 3) kNN of the previous state in one launch:
+ * mpa_fps_f32(fps_xyz [B,fps_N,3] -> fps_idx [B,fps_S], fps_out_xyz) and
+ * mpa_knn_f32(knn_base [B,N,3], knn_query [B,S,3], K) -> (out_dist, out_idx); the two are independent
+ * (neither reads what the other writes).  FPS occupies one workgroup per cloud for fps_S serial
+ * iterations, the search fills the rest of the chip meanwhile.  Shapes outside the fused kernel's
+ * range (fps_N in (128, 2048], K <= 8) are issued as the two separate launches. */
+int mpa_fps_knn_xyz_f32(const float *fps_xyz, int B, int fps_N, int fps_S, const int64_t *start_idx,
+                        int64_t *fps_idx, float *fps_out_xyz, const float *knn_base,
+                        const float *knn_query, int N, int S, int K, float *out_dist, int64_t *out_idx,
+                        void *stream);
+
 /* ---- query_ball_point: modules/pointnet2_utils.py:112-134.  First `nsample` base indices with
  * not (d > radius2), padded with the first hit; a row without hits is filled with N. */
 int mpa_ball_query_f32(const float *base, const float *query, int B, int N, int S, int C,

@@ -15,6 +15,7 @@
 // HBM traffic is 12*N + 8*S (+12*S) bytes per cloud; the kernel is latency bound by design
 // (S serial iterations), see DESIGN.md.
 #include "mpa_common.h"
+#include "fps_body.h"
 
 namespace {
 
@@ -24,78 +25,8 @@ __global__ __launch_bounds__(WAVES * 64) void fps_kernel(const float *__restrict
                                                          int64_t *__restrict__ out_idx,
                                                          float *__restrict__ out_xyz)
 {
-    constexpr int T = WAVES * 64;
-    constexpr int NP = T * P;
     extern __shared__ float lds[];
-    float *sx = lds, *sy = lds + NP, *sz = lds + 2 * NP;
-    uint2 *slot = reinterpret_cast<uint2 *>(lds + 3 * NP);   // [2][WAVES]
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int b = blockIdx.x;
-    const float *cloud = xyz + (size_t)b * N * 3;
-
-    for (int i = tid; i < N * 3; i += T) {
-        int n = i / 3;
-        lds[(i - 3 * n) * NP + n] = cloud[i];
-    }
-    __syncthreads();
-
-    float px[P], py[P], pz[P], md[P];
-    const int first = tid * P;
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
-        int n = first + p;
-        bool ok = n < N;
-        px[p] = ok ? sx[n] : 0.f;
-        py[p] = ok ? sy[n] : 0.f;
-        pz[p] = ok ? sz[n] : 0.f;
-        md[p] = ok ? 1e10f : 0.f;   // padding points stay at 0 and can never win a maximum
-    }
-
-    int far = (int)start[b];
-    int par = 0;
-    for (int it = 0; it < S; ++it) {
-        float cx = sx[far], cy = sy[far], cz = sz[far];
-        if (tid == 0) {
-            out_idx[(size_t)b * S + it] = far;
-            if (out_xyz) {
-                float *o = out_xyz + ((size_t)b * S + it) * 3;
-                o[0] = cx; o[1] = cy; o[2] = cz;
-            }
-        }
-        unsigned best = 0;
-        int bestp = 0;
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-            float dx = px[p] - cx, dy = py[p] - cy, dz = pz[p] - cz;
-            float dd = (dx * dx + dy * dy) + dz * dz;
-            float m = md[p];
-            m = dd < m ? dd : m;
-            md[p] = m;
-            unsigned ub = __float_as_uint(m);
-            if (ub > best) { best = ub; bestp = p; }
-        }
-        unsigned wmax = wave_max_u32(best);
-        unsigned long long hit = __ballot(best == wmax);
-        int wl = __ffsll((long long)hit) - 1;
-        int widx = __builtin_amdgcn_readlane(first + bestp, wl);
-        if (WAVES == 1) {
-            far = widx;
-        } else {
-            if (lane == 0) slot[par * WAVES + wave] = make_uint2(wmax, (unsigned)widx);
-            __syncthreads();
-            uint2 bst = slot[par * WAVES];
-#pragma unroll
-            for (int w = 1; w < WAVES; ++w) {
-                uint2 s = slot[par * WAVES + w];
-                if (s.x > bst.x) bst = s;
-            }
-            far = (int)bst.y;
-            par ^= 1;
-        }
-    }
+    fps_body<WAVES, P>(xyz, N, S, start, out_idx, out_xyz, blockIdx.x, lds);
 }
 
 template <int WAVES, int P>

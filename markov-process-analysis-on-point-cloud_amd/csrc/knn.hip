@@ -11,6 +11,7 @@
 //   dist  : fl(fl(fl(-2*dot) + |q|^2) + |b|^2)                                 (A3)
 // Ties keep the lower base index (strict < on an ascending scan), the order a stable sort gives.
 #include "mpa_common.h"
+#include "fps_body.h"
 #include <cstdlib>
 
 namespace {
@@ -386,16 +387,14 @@ constexpr int KNN_CAP = 32;      // candidates kept per query in pass B
 constexpr int KNN_G = 32;        // groups per query in pass A
 
 template <int CT, int WAVES, int KMAX>
-__global__ __launch_bounds__(WAVES * 64) void knn_mfma_kernel(const float *__restrict__ base,
-                                                              const float *__restrict__ query, int N, int S, int K,
-                                                              float *__restrict__ out_dist,
-                                                              int64_t *__restrict__ out_idx)
+__device__ __forceinline__ void knn_mfma_body(const float *__restrict__ base, const float *__restrict__ query, int N,
+                                              int S, int K, float *__restrict__ out_dist,
+                                              int64_t *__restrict__ out_idx, const int bx, const int by, float *lds)
 {
     constexpr int CP = (CT + 3) & ~3;            // channels padded to a float4 multiple (C=3 -> 4)
     constexpr int PITCH = CP + 4;                // LDS row pitch: (PITCH/4) odd -> conflict-free b128 rows
     constexpr int NV = 32 * CP / 4 / 64;         // float4 staged per lane per tile (CP >= 8)
     constexpr int NT_ = WAVES * 64;
-    extern __shared__ float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
     float *slab = lds + wave * (32 * PITCH + 32);          // [32][PITCH] tile + [32] norms
@@ -406,8 +405,8 @@ __global__ __launch_bounds__(WAVES * 64) void knn_mfma_kernel(const float *__res
     float *cand_d = reinterpret_cast<float *>(cnt + 64);                    // [32][KNN_CAP]
     int *cand_i = reinterpret_cast<int *>(cand_d + 32 * KNN_CAP);           // [32][KNN_CAP]
 
-    const int b = blockIdx.y;
-    const int q0 = blockIdx.x * 32;
+    const int b = by;
+    const int q0 = bx * 32;
     const float *bp = base + (size_t)b * N * CT;
     const int qrow_i = min(q0 + l31, S - 1);
     const float *qp = query + ((size_t)b * S + qrow_i) * CT;
@@ -636,6 +635,37 @@ __global__ __launch_bounds__(WAVES * 64) void knn_mfma_kernel(const float *__res
 }
 
 template <int CT, int WAVES, int KMAX>
+__global__ __launch_bounds__(WAVES * 64) void knn_mfma_kernel(const float *__restrict__ base,
+                                                              const float *__restrict__ query, int N, int S, int K,
+                                                              float *__restrict__ out_dist,
+                                                              int64_t *__restrict__ out_idx)
+{
+    extern __shared__ float lds[];
+    knn_mfma_body<CT, WAVES, KMAX>(base, query, N, S, K, out_dist, out_idx, blockIdx.x, blockIdx.y, lds);
+}
+
+// Farthest point sampling of one point-set state and the xyz-space kNN of the state before it in ONE
+// launch: FPS keeps 1 workgroup per cloud busy for S serial iterations (64 of 256 CUs at batch 64),
+// the kNN's (S/32)*B workgroups fill the rest of the chip meanwhile.  Both read coordinates only
+// and are independent of each other: workgroups [0, B) sample, the others search.
+template <int P>
+__global__ __launch_bounds__(256) void fps_knn3_kernel(const float *__restrict__ fxyz, int fN, int fS,
+                                                       const int64_t *__restrict__ start,
+                                                       int64_t *__restrict__ f_idx, float *__restrict__ f_out_xyz,
+                                                       int B, const float *__restrict__ base,
+                                                       const float *__restrict__ query, int N, int S, int K,
+                                                       float *__restrict__ out_dist, int64_t *__restrict__ out_idx)
+{
+    extern __shared__ float lds[];
+    if ((int)blockIdx.x < B) {
+        fps_body<4, P>(fxyz, fN, fS, start, f_idx, f_out_xyz, blockIdx.x, lds);
+    } else {
+        const int r = blockIdx.x - B, qb = (S + 31) / 32;
+        knn_mfma_body<3, 4, 8>(base, query, N, S, K, out_dist, out_idx, r % qb, r / qb, lds);
+    }
+}
+
+template <int CT, int WAVES, int KMAX>
 int launch_knn_mfma(const float *base, const float *query, int B, int N, int S, int K, float *od, int64_t *oi,
                     hipStream_t st)
 {
@@ -748,6 +778,45 @@ extern "C" int mpa_knn_f32(const float *base, const float *query, int B, int N, 
     case 64: return launch_knn_k<64>(base, query, B, N, S, C, K, out_dist, out_idx, st);
     default: return launch_knn_k<0>(base, query, B, N, S, C, K, out_dist, out_idx, st);
     }
+}
+
+extern "C" int mpa_fps_f32(const float *xyz, int B, int N, int S, const int64_t *start_idx, int64_t *out_idx,
+                           float *out_xyz, void *stream);
+
+extern "C" int mpa_fps_knn_xyz_f32(const float *fps_xyz, int B, int fps_N, int fps_S, const int64_t *start_idx,
+                                   int64_t *fps_idx, float *fps_out_xyz, const float *knn_base,
+                                   const float *knn_query, int N, int S, int K, float *out_dist, int64_t *out_idx,
+                                   void *stream)
+{
+    MPA_CLEAR_ERROR();
+    if (!fps_xyz || !start_idx || !fps_idx || !knn_base || !knn_query || !out_idx || B <= 0 || fps_N <= 0 ||
+        fps_S <= 0 || N <= 0 || S <= 0 || K <= 0)
+        return MPA_EINVAL;
+    if (K > 32 || K > N) return MPA_EUNSUPPORTED;
+    static const bool fused_on = getenv("MPA_NO_FPS_KNN_FUSION") == nullptr;
+    const long long blocks = (long long)B + (long long)mpa_ceil_div(S, 32) * B;
+    if (fused_on && K <= 8 && fps_N > 128 && fps_N <= 2048 && blocks < 0x7fffffffLL) {
+        constexpr size_t knn_work = ((size_t)4 * (32 * (4 + 4) + 32) + KNN_G * 32 + 32 + 64 + 2 * 32 * KNN_CAP) * sizeof(float);
+        constexpr size_t knn_merge = (size_t)32 * 2 * 4 * 8 * 8;
+        constexpr size_t knn_lds = knn_work > knn_merge ? knn_work : knn_merge;
+        const int P = fps_N <= 256 ? 1 : (fps_N <= 512 ? 2 : (fps_N <= 1024 ? 4 : 8));
+        const size_t fps_lds = (size_t)3 * 256 * P * sizeof(float) + 2 * 4 * sizeof(uint2);
+        const size_t lds = fps_lds > knn_lds ? fps_lds : knn_lds;
+        hipStream_t st = (hipStream_t)stream;
+#define MPA_FUSED_CASE(PP)                                                                                           \
+    hipLaunchKernelGGL(fps_knn3_kernel<PP>, dim3((unsigned)blocks), dim3(256), lds, st, fps_xyz, fps_N, fps_S, start_idx, \
+                       fps_idx, fps_out_xyz, B, knn_base, knn_query, N, S, K, out_dist, out_idx)
+        if (P == 1) MPA_FUSED_CASE(1);
+        else if (P == 2) MPA_FUSED_CASE(2);
+        else if (P == 4) MPA_FUSED_CASE(4);
+        else MPA_FUSED_CASE(8);
+#undef MPA_FUSED_CASE
+        MPA_LAUNCH_CHECK();
+        return MPA_OK;
+    }
+    int rc = mpa_fps_f32(fps_xyz, B, fps_N, fps_S, start_idx, fps_idx, fps_out_xyz, stream);
+    if (rc != MPA_OK) return rc;
+    return mpa_knn_f32(knn_base, knn_query, B, N, S, 3, K, out_dist, out_idx, stream);
 }
 
 extern "C" int mpa_ball_query_f32(const float *base, const float *query, int B, int N, int S, int C,

@@ -101,6 +101,38 @@ def _i64(t):
 
 
 # ------------------------------------------------------------------------------- sampling
+def _fps_start(B, N, device, start_idx=None):
+    """First index of every cloud: from the global CPU generator exactly as in the reference
+    (torch.randint on CPU, then moved), or from the graph-safe feeder when one is installed."""
+    if start_idx is None and _FPS_START_HOOK is not None:
+        return _FPS_START_HOOK(B, N, device)          # runtime.FpsStartFeeder
+    if start_idx is None:
+        start_idx = torch.randint(0, N, (B,), dtype=torch.long)
+    if not start_idx.is_cuda and (int(start_idx.min()) < 0 or int(start_idx.max()) >= N):
+        raise ValueError("farthest_point_sample: start_idx out of range")
+    return start_idx.to(device=device, dtype=torch.int64).contiguous()
+
+
+def fps_and_knn_xyz(fps_in, npoint, k, knn_base, knn_query, start_idx=None):
+    """farthest_point_sample(fps_in, npoint, return_xyz=True) and knn_point(k, knn_base, knn_query) on
+    coordinates, as ONE launch (the sampling keeps one workgroup per cloud busy, the search uses the
+    rest of the chip).  -> (fps_idx, fps_xyz, dist, idx)."""
+    _dev(fps_in, knn_base, knn_query)
+    fps_in, base, query = _f32(fps_in.detach()), _f32(knn_base.detach()), _f32(knn_query.detach())
+    B, fN, C = fps_in.shape
+    N, S = base.shape[1], query.shape[1]
+    if C != 3 or base.shape[2] != 3 or query.shape[2] != 3:
+        raise ValueError("fps_and_knn_xyz works on xyz coordinates (C == 3)")
+    start = _fps_start(B, fN, fps_in.device, start_idx)
+    fidx = torch.empty(B, npoint, dtype=torch.int64, device=fps_in.device)
+    fxyz = torch.empty(B, npoint, 3, dtype=torch.float32, device=fps_in.device)
+    dist = torch.empty(B, S, k, dtype=torch.float32, device=base.device)
+    idx = torch.empty(B, S, k, dtype=torch.int64, device=base.device)
+    _launch("mpa_fps_knn_xyz_f32", _p(fps_in), B, fN, npoint, _p(start), _p(fidx), _p(fxyz), _p(base), _p(query), N, S, k,
+            _p(dist), _p(idx), _stream())
+    return fidx, fxyz, dist, idx
+
+
 def farthest_point_sample(xyz, npoint, cuda=False, start_idx=None, return_xyz=False):
     """reference: modules/pointnet2_utils.py:84-109.  xyz [B,N,3] -> int64 [B,npoint].
     The first index of every cloud comes from the global CPU generator exactly as in the
@@ -110,14 +142,7 @@ def farthest_point_sample(xyz, npoint, cuda=False, start_idx=None, return_xyz=Fa
     B, N, C = xyz.shape
     if C != 3:
         raise ValueError("farthest_point_sample: the gfx950 kernel samples in xyz space (C == 3), got C=%d" % C)
-    if start_idx is None and _FPS_START_HOOK is not None:
-        start = _FPS_START_HOOK(B, N, xyz.device)     # graph-safe feeder (runtime.FpsStartFeeder)
-    else:
-        if start_idx is None:
-            start_idx = torch.randint(0, N, (B,), dtype=torch.long)
-        if not start_idx.is_cuda and (int(start_idx.min()) < 0 or int(start_idx.max()) >= N):
-            raise ValueError("farthest_point_sample: start_idx out of range")
-        start = start_idx.to(device=xyz.device, dtype=torch.int64).contiguous()
+    start = _fps_start(B, N, xyz.device, start_idx)
     out = torch.empty(B, npoint, dtype=torch.int64, device=xyz.device)
     oxyz = torch.empty(B, npoint, 3, dtype=torch.float32, device=xyz.device) if return_xyz else None
     _launch("mpa_fps_f32", _p(xyz), B, N, npoint, _p(start), _p(out), _p(oxyz), _stream())
@@ -224,14 +249,18 @@ def geometry_pass(xyz, npoints, k):
     levels = []
     ctx = torch.cuda.stream(side) if use_side else _NullCtx()
     with ctx, torch.no_grad():
-        base = xyz
-        for i in range(len(npoints) + 1):
+        # level i: kNN(base = state i-1 (state 0 for i = 0), query = state i).  It shares a launch with
+        # the sampling of state i+1 (both need state i only); FPS start indices are drawn in the
+        # reference's order (state 1, 2, ...).
+        L = len(npoints)
+        base, cur_xyz, cur_fps = xyz, xyz, None
+        for i in range(L + 1):
             g = _GeoLevel()
-            if i == 0:
-                g.xyz, g.fps_idx = xyz, None
+            g.xyz, g.fps_idx = cur_xyz, cur_fps
+            if i < L:
+                nxt_fps, nxt_xyz, g.dist, g.idx = fps_and_knn_xyz(cur_xyz, npoints[i], k, base, cur_xyz)
             else:
-                g.fps_idx, g.xyz = farthest_point_sample(base, npoints[i - 1], return_xyz=True)
-            g.dist, g.idx = knn_point(k, base, g.xyz)
+                g.dist, g.idx = knn_point(k, base, cur_xyz)
             g.event = None
             if use_side:
                 g.event = torch.cuda.Event()
@@ -240,7 +269,9 @@ def geometry_pass(xyz, npoints, k):
                     if t is not None and t is not xyz:
                         t.record_stream(cur)
             levels.append(g)
-            base = g.xyz
+            base = cur_xyz
+            if i < L:
+                cur_xyz, cur_fps = nxt_xyz, nxt_fps
     return GeometryPass(levels, side)
 
 

@@ -180,7 +180,16 @@ class _ForcedKnn:
         self.used = [False] * len(self.recorded)
 
     def __call__(self, nsample, xyz, new_xyz):
-        dist, idx = self.real(nsample, xyz, new_xyz)
+        return self.force(*self.real(nsample, xyz, new_xyz))
+
+    def fused(self, real_fused):
+        """wrapper for ops.fps_and_knn_xyz (sampling + xyz kNN in one launch): its kNN half is forced too"""
+        def f(fps_in, npoint, k, knn_base, knn_query, start_idx=None):
+            fidx, fxyz, dist, idx = real_fused(fps_in, npoint, k, knn_base, knn_query, start_idx=start_idx)
+            return (fidx, fxyz) + self.force(dist, idx)
+        return f
+
+    def force(self, dist, idx):
         # the reference's recorded call with this shape that has not been used yet (the geometry
         # pass issues all xyz-space kNNs first; per shape the reference's order is xyz, feature)
         j = next(j for j, r in enumerate(self.recorded) if not self.used[j] and tuple(r.shape) == tuple(idx.shape))
@@ -198,14 +207,17 @@ def _run_model(g, model, run, patch_mods, prefix):
     patch_mods = list(patch_mods) + [_ops]          # geometry_pass calls ops.knn_point directly
     forced = _ForcedKnn(_ops.knn_point, rec)
     saved = [m.knn_point for m in patch_mods]
+    saved_fused = _ops.fps_and_knn_xyz
     for m in patch_mods:
         m.knn_point = forced
+    _ops.fps_and_knn_xyz = forced.fused(saved_fused)
     try:
         torch.manual_seed(2024)
         out = run(model)
     finally:
         for m, s in zip(patch_mods, saved):
             m.knn_point = s
+        _ops.fps_and_knn_xyz = saved_fused
     assert forced.i == len(rec)
     return out, forced
 

@@ -350,3 +350,19 @@ def test_diffattn_forward_backward(ops, monkeypatch, B, N, S, C, K, path):
         err = (got.double() - want).abs()
         assert (err > 1e-4 * scale).float().mean().item() < 1e-4
         assert torch.isfinite(got).all()
+
+
+@pytest.mark.parametrize("B,fN,fS,N,S", [(4, 1024, 512, 1024, 1024), (3, 512, 256, 1024, 512), (2, 256, 128, 512, 256),
+                                         (2, 2048, 1024, 2048, 2048), (2, 64, 32, 128, 64), (5, 300, 100, 300, 300)])
+def test_fused_fps_knn_xyz_equals_separate_launches(ops, B, fN, fS, N, S):
+    """mpa_fps_knn_xyz_f32 (one launch: sampling + xyz kNN side by side) == the two entry points."""
+    base = unit_cloud(B, N, seed=fN + S)
+    query = base[:, :S].contiguous()
+    fin = (query if fN == S else unit_cloud(B, fN, seed=7))
+    start = torch.randint(0, fN, (B,), generator=torch.Generator().manual_seed(1))
+    base, query, fin = base.cuda(), query.cuda(), fin.cuda()
+    fidx, fxyz, dist, idx = ops.fps_and_knn_xyz(fin, fS, 8, base, query, start_idx=start)
+    fidx0, fxyz0 = ops.farthest_point_sample(fin, fS, start_idx=start, return_xyz=True)
+    dist0, idx0 = ops.knn_point(8, base, query)
+    assert torch.equal(fidx, fidx0) and torch.equal(fxyz, fxyz0)
+    assert torch.equal(idx, idx0) and torch.equal(bits(dist.cpu().numpy()) if False else dist, dist0)
