@@ -196,6 +196,18 @@ int mpa_bn_act_bwd_apply_f32(const float *x, const float *grad_y, const float *m
                              float slope, int use_batch_stats, int M, int C, int ldg, float *grad_x,
                              float *dgamma, float *dbeta, void *stream);
 
+/* ---- umbrella surface features (RepSurf front-end; reference modules/repsurface_utils.py:106-126,
+ * :321-376, modules/recons_utils.py:27-57,82-90,108-124,152-176, modules/polar_utils.py:10-31).
+ * xyz [B,N,3]; knn_idx [B,N,K] = knn_point(K, xyz, xyz) (entry 0, the point itself, is dropped).
+ * Per point the K-1 neighbour offsets are sorted by azimuth and paired cyclically into triangles
+ * (centre, p_i, p_i+1); out [B,N,K-1,CH] = centre of gravity (3) | its spherical coordinates
+ * rho, theta/pi, phi/2pi+0.5 (3) | unit normal, flipped so that the first triangle's x is positive
+ * and by cloud_sign[b] (+-1, the reference's per-cloud random inversion; NULL = +1) (3) | and, if
+ * return_dist, normal.centre/sqrt(3) (1): CH = 10 or 9.  Degenerate triangles (NaN normal) take
+ * normal, centre and constant of the point's first valid triangle.  K - 1 <= 16.  No backward. */
+int mpa_umbrella_features_f32(const float *xyz, const int64_t *knn_idx, int B, int N, int K,
+                              const float *cloud_sign, int return_dist, float *out, void *stream);
+
 /* ---- upsample: the decoder's coarse->fine transition, modules/pointnet2_utils.py:13-50.
  * points [B,S,C], knn_idx [B,S,K] with values < Nf (= S*scale_ratio).  out [B,Nf,C] is the
  * mean, over the coarse rows s that list fine point n, of points[s]; the divisor counts only

@@ -33,6 +33,7 @@ SIGNATURES = {
     "mpa_gather_fwd_f32": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "mpa_gather_bwd_f32": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "mpa_fps_knn_xyz_f32": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
+    "mpa_umbrella_features_f32": [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp],
     "mpa_diffattn_fwd_f32": [_vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp],
     "mpa_diffattn_bwd_f32": [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp,
                              ctypes.c_size_t, _vp],

@@ -83,6 +83,58 @@ class SurfaceAbstractionCD(nn.Module):
         return new_center.permute(0, 2, 1), new_normal.permute(0, 2, 1), new_feature
 
 
+def group_by_umbrella(xyz, new_xyz, k=9, cuda=False):
+    """reference :106-126.  [B,N',k-1,3 (centre, p_i, p_i+1),3]: the k-1 nearest neighbours of each
+    point of new_xyz (the nearest dropped), relative to it, sorted by azimuth, paired cyclically."""
+    from .polar_utils import xyz2sphere
+    idx = query_knn_point(k, xyz, new_xyz)
+    rel = index_points(xyz, idx)[:, :, 1:] - new_xyz.unsqueeze(-2)
+    order = xyz2sphere(rel)[..., 2].argsort(dim=-1, stable=True)
+    srt = torch.gather(rel, 2, order.unsqueeze(-1).expand(-1, -1, -1, 3)).unsqueeze(-2)
+    return torch.cat([torch.zeros_like(srt), srt, torch.roll(srt, -1, dims=-3)], dim=-2)
+
+
+class UmbrellaSurfaceConstructor(nn.Module):
+    """Umbrella-based surface abstraction (reference :321-376): per point the k-1 triangles around it
+    -> (centre | polar | normal | position) -> three 1x1 convolutions (BatchNorm + ReLU after the
+    first two) -> sum / mean / max over the triangles.  [B,3,N] -> [B,in_channel,N].
+    The triangle features come from one fused kernel (ops.umbrella_features), the convolutions run
+    as the fp32-MFMA Linear unit over the B*N*(k-1) rows; parameter names equal the reference's."""
+
+    def __init__(self, k, in_channel, aggr_type='sum', return_dist=False, random_inv=True, cuda=False):
+        super().__init__()
+        self.k = k
+        self.return_dist = return_dist
+        self.random_inv = random_inv
+        self.aggr_type = aggr_type
+        self.cuda_ops = cuda      # the reference stores this as `self.cuda`, shadowing nn.Module.cuda
+        self.mlps = nn.Sequential(
+            nn.Conv2d(in_channel, in_channel, 1, bias=False), nn.BatchNorm2d(in_channel), nn.ReLU(True),
+            nn.Conv2d(in_channel, in_channel, 1, bias=True), nn.BatchNorm2d(in_channel), nn.ReLU(True),
+            nn.Conv2d(in_channel, in_channel, 1, bias=True))
+
+    def forward(self, center):
+        center = center.permute(0, 2, 1).contiguous()
+        B, N, _ = center.shape
+        sign = None
+        if self.random_inv:       # per-cloud flip drawn from the CPU generator, as the reference does
+            sign = torch.randint(0, 2, (B, 1, 1)).float().view(B) * 2. - 1.
+        f = ops.umbrella_features(center, self.k, cloud_sign=sign, return_dist=self.return_dist)   # [B,N,G,CH]
+        G, CH = f.shape[2], f.shape[3]
+        m = self.mlps
+        x = f.view(B, N * G, CH)
+        x = ops.linear_bn_act(x, m[0].weight.view(CH, CH), None, m[1], 0.0)
+        x = ops.linear_bn_act(x, m[3].weight.view(CH, CH), m[3].bias, m[4], 0.0)
+        x = ops.linear(x, m[6].weight.view(CH, CH), m[6].bias).view(B, N, G, CH)
+        if self.aggr_type == 'max':
+            x = x.max(dim=2)[0]
+        elif self.aggr_type == 'avg':
+            x = x.mean(dim=2)
+        else:
+            x = x.sum(dim=2)
+        return x.permute(0, 2, 1)
+
+
 class LocalMerge(nn.Module):
     """State -> state probability-transition block, classification variant (reference :406-446):
     xyz-space and feature-space neighbourhoods, two attention streams, fc2 over 2*out.

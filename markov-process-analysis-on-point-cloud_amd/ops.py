@@ -283,6 +283,26 @@ class _NullCtx:
         return False
 
 
+# ------------------------------------------------------------------------------- umbrella surfaces
+def umbrella_features(xyz, k=9, cloud_sign=None, return_dist=True):
+    """RepSurf umbrella surface features of every point (reference modules/repsurface_utils.py:106-126 +
+    the feature part of UmbrellaSurfaceConstructor.forward :350-364): xyz [B,N,3] -> [B,N,k-1,10|9]
+    = triangle centre | its spherical coordinates | unit normal | (plane constant).  cloud_sign [B]
+    of +-1: the per-cloud random inversion of the normals (None: none).  Coordinates only: no gradient."""
+    _dev(xyz)
+    with torch.no_grad():
+        xyz = _f32(xyz.detach())
+        B, N, C = xyz.shape
+        if C != 3:
+            raise ValueError("umbrella_features works on xyz coordinates (C == 3)")
+        idx = knn_point(k, xyz, xyz)[1]
+        sign = None if cloud_sign is None else cloud_sign.to(device=xyz.device, dtype=torch.float32).contiguous()
+        out = torch.empty(B, N, k - 1, 10 if return_dist else 9, dtype=torch.float32, device=xyz.device)
+        _launch("mpa_umbrella_features_f32", _p(xyz), _p(idx), B, N, k, _p(sign), int(bool(return_dist)), _p(out),
+                _stream())
+    return out
+
+
 # ------------------------------------------------------------------------------- gathers
 class _IndexPoints(torch.autograd.Function):
     @staticmethod

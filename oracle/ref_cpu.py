@@ -25,6 +25,9 @@ Reference locations restated here (paths under Markov_Process_Analysis_on_Point_
   PointNetFeaturePropagation       modules/pointnet2_utils.py:860-912
   cls Model / seg get_model        models/repsurf/repsurf_ssg_umb.py:35-70 / pointnet2_part_seg_msg.py:33-156
   SmoothClsLoss / get_loss         util/utils.py:74-88 / pointnet2_part_seg_msg.py:159-180
+  xyz2sphere                       modules/polar_utils.py:10-31
+  cal_normal / cal_center / cal_const / check_nan_umb   modules/recons_utils.py:27-57,82-90,108-124,152-176
+  group_by_umbrella / UmbrellaSurfaceConstructor        modules/repsurface_utils.py:106-126,321-376
 """
 import math
 
@@ -455,3 +458,84 @@ def smooth_cls_loss(pred, target, eps=0.1):
 def partseg_loss(pred, target, eps=0.1):
     """pointnet2_part_seg_msg.py:159-180 -- pred are logits [M, n_class]."""
     return smooth_cls_loss(F.log_softmax(pred, dim=1), target.contiguous().view(-1), eps)
+
+
+# ----------------------------------------------------------------------------- umbrella front-end
+def xyz2sphere(xyz, normalize=True):
+    """(rho, theta, phi) of [..., 3] coordinates; theta is 0 where rho is 0; normalised to [0, 1]."""
+    rho = xyz.pow(2).sum(-1, keepdim=True).sqrt().clamp(min=0)
+    theta = torch.acos(xyz[..., 2:3] / rho)
+    phi = torch.atan2(xyz[..., 1:2], xyz[..., 0:1])
+    theta = torch.where(rho == 0, torch.zeros_like(theta), theta)
+    if normalize:
+        theta = theta / math.pi
+        phi = phi / (2 * math.pi) + .5
+    return torch.cat([rho, theta, phi], -1)
+
+
+def group_by_umbrella(xyz, new_xyz, k=9):
+    """[B,N',k-1,3 (triangle vertices: centre, p_i, p_i+1), 3]: the k-1 nearest neighbours of every
+    point (the nearest -- the point itself -- dropped), relative to the point, sorted by azimuth,
+    each paired with its successor (cyclically)."""
+    idx = knn_point(k, xyz, new_xyz)[1]
+    rel = index_points(xyz, idx)[:, :, 1:] - new_xyz.unsqueeze(-2)
+    order = xyz2sphere(rel)[..., 2].argsort(dim=-1)
+    srt = torch.gather(rel, 2, order.unsqueeze(-1).expand(-1, -1, -1, 3)).unsqueeze(-2)
+    return torch.cat([torch.zeros_like(srt), srt, torch.roll(srt, -1, dims=-3)], dim=-2)
+
+
+def cal_normal_umb(group_xyz, random_inv=False):
+    """Unit normals of the triangles [B,N,G,3,3]; all G normals of a point are flipped by the sign of
+    the FIRST triangle's x component; optional per-cloud random flip drawn from the CPU generator."""
+    nor = torch.cross(group_xyz[..., 1, :] - group_xyz[..., 0, :], group_xyz[..., 2, :] - group_xyz[..., 0, :], dim=-1)
+    unit = nor / torch.norm(nor, dim=-1, keepdim=True)
+    unit = unit * ((unit[..., 0:1, 0] > 0).float() * 2. - 1.).unsqueeze(-1)
+    if random_inv:
+        rnd = (torch.randint(0, 2, (group_xyz.size(0), 1, 1)).float() * 2. - 1.).to(unit.device)
+        unit = unit * rnd.unsqueeze(-1)
+    return unit
+
+
+def check_nan_umb(normal, center, pos):
+    """Triangles whose normal is NaN (degenerate) take the values of the point's first valid triangle."""
+    B, N, G, _ = normal.shape
+    bad = torch.isnan(normal).any(-1)
+    first = torch.argmax((~bad).int(), dim=-1)
+    pick = first.view(B, N, 1, 1)
+    out = []
+    for t in (normal, center, pos):
+        rep = torch.gather(t, 2, pick.expand(-1, -1, 1, t.shape[-1])).expand(-1, -1, G, -1)
+        out.append(torch.where(bad.unsqueeze(-1), rep, t))
+    return out
+
+
+class UmbrellaSurfaceConstructor(nn.Module):
+    """Umbrella surface features (centre 3 | polar 3 | normal 3 | position 1) of the k-1 triangles
+    around every point, three 1x1 convolutions (BN + ReLU after the first two), summed over the
+    triangles.  [B,3,N] -> [B,10,N]."""
+
+    def __init__(self, k, in_channel, aggr_type='sum', return_dist=False, random_inv=True, cuda=False):
+        super().__init__()
+        self.k, self.return_dist, self.random_inv, self.aggr_type = k, return_dist, random_inv, aggr_type
+        self.mlps = nn.Sequential(
+            nn.Conv2d(in_channel, in_channel, 1, bias=False), nn.BatchNorm2d(in_channel), nn.ReLU(True),
+            nn.Conv2d(in_channel, in_channel, 1, bias=True), nn.BatchNorm2d(in_channel), nn.ReLU(True),
+            nn.Conv2d(in_channel, in_channel, 1, bias=True))
+
+    def features(self, center):
+        tri = group_by_umbrella(center, center, k=self.k)
+        normal = cal_normal_umb(tri, random_inv=self.random_inv)
+        cen = tri.mean(dim=-2)
+        polar = xyz2sphere(cen)
+        if self.return_dist:
+            pos = (normal * cen).sum(-1, keepdim=True) / torch.sqrt(torch.tensor([3.0]))
+            normal, cen, pos = check_nan_umb(normal, cen, pos)
+            return torch.cat([cen, polar, normal, pos], dim=-1)
+        normal, cen, _ = check_nan_umb(normal, cen, cen[..., :1])
+        return torch.cat([cen, polar, normal], dim=-1)
+
+    def forward(self, center):
+        f = self.mlps(self.features(center.permute(0, 2, 1)).permute(0, 3, 2, 1))
+        if self.aggr_type == 'max':
+            return f.max(2)[0]
+        return f.mean(2) if self.aggr_type == 'avg' else f.sum(2)

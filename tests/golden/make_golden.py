@@ -232,6 +232,43 @@ def gen_sa():
     save("sa.npz", d)
 
 
+# ------------------------------------------------------------------ umbrella surface front-end
+def gen_umbrella():
+    import importlib
+    recons = importlib.import_module("modules.recons_utils")
+    polar = importlib.import_module("modules.polar_utils")
+    d = {}
+    B, N = 2, 512
+    xyz = unit_cloud(B, N, seed=1234)
+    xyz[0, 7] = xyz[0, 3]                      # a duplicated point: degenerate triangles -> the NaN replacement path
+    d["xyz"] = npy(xyz)
+    tri = rs.group_by_umbrella(xyz, xyz, k=9)
+    d["triangles"] = npy(tri)
+    normal = recons.cal_normal(tri, random_inv=False, is_group=True)
+    center = recons.cal_center(tri)
+    pol = polar.xyz2sphere(center)
+    pos = recons.cal_const(normal, center)
+    normal, center, pos = recons.check_nan_umb(normal, center, pos)
+    d["features"] = npy(torch.cat([center, pol, normal, pos], dim=-1))          # [B,N,8,10]
+    for tag, rinv in (("det", False), ("rinv", True)):
+        m = fill_state(rs.UmbrellaSurfaceConstructor(9, 10, aggr_type='sum', return_dist=True, random_inv=rinv,
+                                                     cuda=False), seed=13).train()
+        torch.manual_seed(77)
+        out = m(xyz.transpose(1, 2).clone())
+        d[tag + "/out"] = npy(out)
+        (out * randn(out.shape, seed=5)).sum().backward()
+        for n, p_ in m.named_parameters():
+            d[tag + "/grad." + n] = npy(p_.grad)
+        for n, b_ in m.named_buffers():
+            if "running" in n:
+                d[tag + "/buf." + n] = npy(b_)
+    m = fill_state(rs.UmbrellaSurfaceConstructor(9, 10, aggr_type='sum', return_dist=True, random_inv=False,
+                                                 cuda=False), seed=13).eval()
+    with torch.no_grad():
+        d["eval/out"] = npy(m(xyz.transpose(1, 2).clone()))
+    save("umbrella.npz", d)
+
+
 # ------------------------------------------------------------------ whole models
 def model_golden(model, run, params_full):
     """run(model) -> output tensor.  Returns eval output, train output, loss grads."""
@@ -342,7 +379,9 @@ def gen_seg():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["index", "blocks", "fuse", "sa", "cls", "seg"]
+    which = sys.argv[1:] or ["index", "blocks", "fuse", "sa", "umbrella", "cls", "seg"]
+    if "umbrella" in which:
+        gen_umbrella()
     if "sa" in which:
         gen_sa()
     if "index" in which:

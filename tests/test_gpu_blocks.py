@@ -459,3 +459,35 @@ def test_flat_buffers_keep_stacked_projections_adjacent(RS):
         st = ops._stacked_all(group)
         assert st.data_ptr() == group[0].data_ptr(), "stacked parameters are not adjacent in the flat buffer"
         assert torch.equal(st, torch.cat([g.detach() for g in group], 0))
+
+
+# --------------------------------------------------------------------- umbrella surface front-end
+def test_umbrella_surface_constructor(RS):
+    """fused umbrella feature kernel + the 1x1-convolution MLP on the MFMA Linear unit
+    against the reference (tests/golden/umbrella.npz; one duplicated point -> degenerate triangles)."""
+    import mpa_amd  # noqa: F401
+    from mpa_amd import ops
+    from conftest import load_golden
+    g = load_golden("umbrella.npz")
+    xyz = G(g["xyz"])
+    f = ops.umbrella_features(xyz, 9, return_dist=True)
+    ref = g["features"]
+    # spherical coordinates go through acosf/atan2f (a few ulp from the host's libm); the rest is exact-ish
+    assert np.abs(f.cpu().numpy() - ref).max() < 2e-6 * max(1.0, np.abs(ref).max())
+    tri = RS.group_by_umbrella(xyz, xyz, k=9)
+    assert np.array_equal(tri.cpu().numpy(), g["triangles"])
+    for tag, rinv in (("det", False), ("rinv", True)):
+        m = fill_state(RS.UmbrellaSurfaceConstructor(9, 10, aggr_type="sum", return_dist=True, random_inv=rinv), seed=13).cuda().train()
+        torch.manual_seed(77)
+        out = m(xyz.transpose(1, 2).contiguous())
+        close(out, g[tag + "/out"], what="umbrella constructor (%s)" % tag)
+        (out * randn(out.shape, seed=5).cuda()).sum().backward()
+        gs = max(float(np.abs(g[k]).max()) for k in g if k.startswith(tag + "/grad."))
+        for n, p in m.named_parameters():
+            close(p.grad, g[tag + "/grad." + n], what="umbrella grad " + n, scale=gs)
+        for n, b in m.named_buffers():
+            if "running" in n:
+                close(b, g[tag + "/buf." + n], what="umbrella " + n)
+    m = fill_state(RS.UmbrellaSurfaceConstructor(9, 10, aggr_type="sum", return_dist=True, random_inv=False), seed=13).cuda().eval()
+    with torch.no_grad():
+        close(m(xyz.transpose(1, 2).contiguous()), g["eval/out"], what="umbrella constructor (eval)")

@@ -218,3 +218,28 @@ def test_ref_cpu_seg_model(golden_seg):
     model.drop1.p = 0.0
     pts, lab = T(golden_seg["points"]), T(golden_seg["label"])
     _check_model(golden_seg, model, lambda m: m(pts, lab)[0])
+
+
+def test_ref_cpu_umbrella_front_end():
+    """the oracle's restatement of group_by_umbrella / cal_normal / cal_center / xyz2sphere /
+    cal_const / check_nan_umb / UmbrellaSurfaceConstructor against vectors produced by the reference."""
+    from conftest import load_golden
+    g = load_golden("umbrella.npz")
+    xyz = torch.from_numpy(g["xyz"])
+    torch.set_num_threads(1)
+    tri = R.group_by_umbrella(xyz, xyz, k=9)
+    assert np.array_equal(tri.numpy(), g["triangles"])
+    m = fill_state(R.UmbrellaSurfaceConstructor(9, 10, aggr_type="sum", return_dist=True, random_inv=False), seed=13)
+    assert np.array_equal(m.features(xyz).numpy(), g["features"])
+    for tag, rinv in (("det", False), ("rinv", True)):
+        m = fill_state(R.UmbrellaSurfaceConstructor(9, 10, aggr_type="sum", return_dist=True, random_inv=rinv), seed=13).train()
+        torch.manual_seed(77)
+        out = m(xyz.transpose(1, 2).clone())
+        assert np.abs(out.detach().numpy() - g[tag + "/out"]).max() < 1e-6 * np.abs(g[tag + "/out"]).max()
+        (out * randn(out.shape, seed=5)).sum().backward()
+        for n, p in m.named_parameters():
+            ref = g[tag + "/grad." + n]
+            assert np.abs(p.grad.numpy() - ref).max() < 1e-5 * max(1.0, np.abs(ref).max()), n
+    m = fill_state(R.UmbrellaSurfaceConstructor(9, 10, aggr_type="sum", return_dist=True, random_inv=False), seed=13).eval()
+    with torch.no_grad():
+        assert np.abs(m(xyz.transpose(1, 2).clone()).numpy() - g["eval/out"]).max() < 1e-6 * np.abs(g["eval/out"]).max()
