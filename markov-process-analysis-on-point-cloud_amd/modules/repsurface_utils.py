@@ -4,9 +4,8 @@ same names, signatures and state-dict keys; device work in libmpa_hip.so.
 Reference locations (Markov_Process_Analysis_on_Point_Cloud/modules/repsurface_utils.py):
   sample_and_group:12  square_distance:129  farthest_point_sample:150  index_points:174
   knn_point:193  SurfaceAbstractionCD:256  Linear:380  LocalMerge:406  LocalTrans:448
-  KeepHighResolutionModule:542
-The RepSurf umbrella/polar feature engineering (UmbrellaSurfaceConstructor, polar_utils,
-recons_utils) is outside the Markov path and is not provided.
+  KeepHighResolutionModule:542  group_by_umbrella:106  UmbrellaSurfaceConstructor:321
+(polar_utils / recons_utils: the sibling modules of the same names).
 """
 import torch
 import torch.nn as nn
@@ -20,16 +19,17 @@ from .pointnet2_utils import Linear, LocalTrans, local_trans_pair, stacked_param
 
 def sample_and_group(npoint, radius, nsample, center, normal, feature, return_normal=True, return_polar=False,
                      cuda=False):
-    """reference :12-56 -- FPS, ball query, centre-relative grouping of xyz | normal | feature.
-    `return_polar` needs the out-of-scope polar front-end and is rejected."""
-    if return_polar:
-        raise NotImplementedError("polar features belong to the RepSurf front-end (out of scope, SURVEY.md 8f)")
+    """reference :12-56 -- FPS, ball query, centre-relative grouping of xyz (| its spherical
+    coordinates, `return_polar`) | normal | feature."""
     fps_idx = farthest_point_sample(center, npoint)
     new_center = index_points(center, fps_idx)
     new_normal = index_points(normal, fps_idx)
     idx = query_ball_point(radius, nsample, center, new_center, cuda=cuda)
     group_normal = index_points(normal, idx)
     group_center_norm = index_points(center, idx) - new_center.unsqueeze(2)
+    if return_polar:
+        from .polar_utils import xyz2sphere
+        group_center_norm = torch.cat([group_center_norm, xyz2sphere(group_center_norm)], dim=-1)
     if feature is not None:
         group_feature = index_points(feature, idx)
         parts = [group_center_norm, group_normal, group_feature] if return_normal else [group_center_norm,

@@ -229,6 +229,15 @@ def gen_sa():
     torch.manual_seed(21)
     oc, on, of = m(xyz.transpose(1, 2), nrm.transpose(1, 2), feat.transpose(1, 2))
     d["sa/center"], d["sa/normal"], d["sa/feature"] = npy(oc), npy(on), npy(of)
+    # the same with the spherical coordinates of the grouped offsets (return_polar)
+    torch.manual_seed(21)
+    c, n, f = rs.sample_and_group(128, 0.2, 24, xyz, nrm, feat, return_normal=True, return_polar=True, cuda=False)
+    d["sgp/feature"] = npy(f)
+    m = fill_state(rs.SurfaceAbstractionCD(npoint=128, radius=0.2, nsample=24, feat_channel=16 + 3, pos_channel=6,
+                                           mlp=[32, 64], group_all=False, return_polar=True, cuda=False), seed=8).train()
+    torch.manual_seed(21)
+    oc, on, of = m(xyz.transpose(1, 2), nrm.transpose(1, 2), feat.transpose(1, 2))
+    d["sap/feature"] = npy(of)
     save("sa.npz", d)
 
 

@@ -387,6 +387,15 @@ def test_sample_and_group_and_surface_abstraction(RS):
     oc, on, of = m(xyz.transpose(1, 2), nrm.transpose(1, 2), feat.transpose(1, 2))
     assert np.array_equal(oc.cpu().numpy(), g["sa/center"])
     close(of, g["sa/feature"], what="SurfaceAbstractionCD features")
+    # return_polar: spherical coordinates of the grouped offsets appended (acos/atan2: a few ulp)
+    torch.manual_seed(21)
+    c, n, f = RS.sample_and_group(128, 0.2, 24, xyz, nrm, feat, return_normal=True, return_polar=True)
+    close(f, g["sgp/feature"], tol=2e-6, what="sample_and_group(return_polar)")
+    m = fill_state(RS.SurfaceAbstractionCD(npoint=128, radius=0.2, nsample=24, feat_channel=16 + 3, pos_channel=6,
+                                           mlp=[32, 64], group_all=False, return_polar=True), seed=8).cuda().train()
+    torch.manual_seed(21)
+    close(m(xyz.transpose(1, 2), nrm.transpose(1, 2), feat.transpose(1, 2))[2], g["sap/feature"],
+          what="SurfaceAbstractionCD(return_polar) features")
 
 
 def test_sample_legacy_helper(P):
