@@ -39,15 +39,35 @@ def sample_and_group(npoint, radius, nsample, center, normal, feature, return_no
     return new_center, new_normal, torch.cat(parts, dim=-1)
 
 
+def sample_and_group_all(center, normal, feature, return_normal=True, return_polar=False):
+    """reference :58-84 -- the whole cloud as one group around the origin."""
+    B, N, C = normal.shape
+    new_center = torch.zeros(B, 1, 3, device=center.device)
+    group_center = center.view(B, 1, N, 3)
+    if return_polar:
+        from .polar_utils import xyz2sphere
+        group_center = torch.cat([group_center, xyz2sphere(group_center)], dim=-1)
+    parts = [group_center, normal.view(B, 1, N, C), feature.view(B, 1, N, -1)] if return_normal else \
+        [group_center, feature.view(B, 1, N, -1)]
+    return new_center, new_center, torch.cat(parts, dim=-1)
+
+
+def _conv_bn(x, conv, bn, slope):
+    """1x1 Conv2d + BatchNorm2d (+ ReLU when slope == 0.0) over [B,S,G,C] rows on the Linear unit."""
+    B, S, G, C = x.shape
+    y = ops.linear_bn_act(x.reshape(B, S * G, C), conv.weight.view(conv.out_channels, conv.in_channels), conv.bias,
+                          bn, slope)
+    return y.view(B, S, G, conv.out_channels)
+
+
 class SurfaceAbstractionCD(nn.Module):
-    """RepSurf set abstraction (reference :256-319): FPS + ball query + shared MLP + max over
-    the group.  The grouping runs on the gfx950 kernels; the 1x1 convolutions are plain torch."""
+    """RepSurf set abstraction (reference :256-319): FPS + ball query (or the whole cloud, group_all)
+    + shared MLP + max over the group.  Grouping on the gfx950 kernels, the 1x1 convolutions with
+    their BatchNorm2d + ReLU as the fp32-MFMA Linear unit over the B*S*nsample rows."""
 
     def __init__(self, npoint, radius, nsample, feat_channel, pos_channel, mlp, group_all, return_normal=True,
                  return_polar=False, cuda=False):
         super().__init__()
-        if group_all:
-            raise NotImplementedError("group_all is not on the Markov path")
         self.npoint, self.radius, self.nsample = npoint, radius, nsample
         self.return_normal, self.return_polar = return_normal, return_polar
         self.cuda_ops = cuda
@@ -70,16 +90,22 @@ class SurfaceAbstractionCD(nn.Module):
         center = center.permute(0, 2, 1).contiguous()
         if feature is not None:
             feature = feature.permute(0, 2, 1).contiguous()
-        new_center, new_normal, new_feature = sample_and_group(self.npoint, self.radius, self.nsample, center, normal,
-                                                               feature, return_normal=self.return_normal,
-                                                               return_polar=self.return_polar, cuda=self.cuda_ops)
-        new_feature = new_feature.permute(0, 3, 2, 1)
-        loc = self.bn_l0(self.mlp_l0(new_feature[:, :self.pos_channel]))
-        feat = self.bn_f0(self.mlp_f0(new_feature[:, self.pos_channel:]))
+        if self.group_all:
+            new_center, new_normal, new_feature = sample_and_group_all(center, normal, feature,
+                                                                       return_normal=self.return_normal,
+                                                                       return_polar=self.return_polar)
+        else:
+            new_center, new_normal, new_feature = sample_and_group(self.npoint, self.radius, self.nsample, center,
+                                                                   normal, feature, return_normal=self.return_normal,
+                                                                   return_polar=self.return_polar, cuda=self.cuda_ops)
+        # [B,S,G,C] rows (the reference permutes to [B,C,G,S] for Conv2d; same arithmetic per row)
+        pc = self.pos_channel
+        loc = _conv_bn(new_feature[..., :pc].contiguous(), self.mlp_l0, self.bn_l0, None)
+        feat = _conv_bn(new_feature[..., pc:].contiguous(), self.mlp_f0, self.bn_f0, None)
         new_feature = F.relu(loc + feat)
         for conv, bn in zip(self.mlp_convs, self.mlp_bns):
-            new_feature = F.relu(bn(conv(new_feature)))
-        new_feature = torch.max(new_feature, 2)[0]
+            new_feature = _conv_bn(new_feature, conv, bn, 0.0)
+        new_feature = new_feature.max(dim=2)[0].permute(0, 2, 1)          # max over the group -> [B,C,S]
         return new_center.permute(0, 2, 1), new_normal.permute(0, 2, 1), new_feature
 
 

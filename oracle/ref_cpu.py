@@ -539,3 +539,89 @@ class UmbrellaSurfaceConstructor(nn.Module):
         if self.aggr_type == 'max':
             return f.max(2)[0]
         return f.mean(2) if self.aggr_type == 'avg' else f.sum(2)
+
+
+# ----------------------------------------------------------------------------- RepSurf baseline (a14)
+def sample_and_group(npoint, radius, nsample, center, normal, feature, return_normal=True, return_polar=False):
+    """modules/repsurface_utils.py:12-56."""
+    fps_idx = farthest_point_sample(center, npoint)
+    new_center, new_normal = index_points(center, fps_idx), index_points(normal, fps_idx)
+    idx = query_ball_point(radius, nsample, center, new_center)
+    rel = index_points(center, idx) - new_center.unsqueeze(2)
+    if return_polar:
+        rel = torch.cat([rel, xyz2sphere(rel)], dim=-1)
+    parts = [rel, index_points(normal, idx)]
+    if feature is not None:
+        parts = [rel, index_points(normal, idx), index_points(feature, idx)] if return_normal else \
+            [rel, index_points(feature, idx)]
+    return new_center, new_normal, torch.cat(parts, dim=-1)
+
+
+def sample_and_group_all(center, normal, feature, return_normal=True, return_polar=False):
+    """modules/repsurface_utils.py:58-84."""
+    B, N, C = normal.shape
+    zero = torch.zeros(B, 1, 3)
+    gc = center.view(B, 1, N, 3)
+    if return_polar:
+        gc = torch.cat([gc, xyz2sphere(gc)], dim=-1)
+    parts = [gc, normal.view(B, 1, N, C), feature.view(B, 1, N, -1)] if return_normal else [gc, feature.view(B, 1, N, -1)]
+    return zero, zero, torch.cat(parts, dim=-1)
+
+
+class SurfaceAbstractionCD(nn.Module):
+    """modules/repsurface_utils.py:256-319."""
+
+    def __init__(self, npoint, radius, nsample, feat_channel, pos_channel, mlp, group_all, return_normal=True,
+                 return_polar=False, cuda=False):
+        super().__init__()
+        self.npoint, self.radius, self.nsample, self.group_all = npoint, radius, nsample, group_all
+        self.return_normal, self.return_polar, self.pos_channel = return_normal, return_polar, pos_channel
+        self.mlp_convs, self.mlp_bns = nn.ModuleList(), nn.ModuleList()
+        self.mlp_l0, self.mlp_f0 = nn.Conv2d(pos_channel, mlp[0], 1), nn.Conv2d(feat_channel, mlp[0], 1)
+        self.bn_l0, self.bn_f0 = nn.BatchNorm2d(mlp[0]), nn.BatchNorm2d(mlp[0])
+        last = mlp[0]
+        for oc in mlp[1:]:
+            self.mlp_convs.append(nn.Conv2d(last, oc, 1))
+            self.mlp_bns.append(nn.BatchNorm2d(oc))
+            last = oc
+
+    def forward(self, center, normal, feature):
+        normal, center = normal.permute(0, 2, 1), center.permute(0, 2, 1)
+        feature = feature.permute(0, 2, 1) if feature is not None else None
+        if self.group_all:
+            nc, nn_, nf = sample_and_group_all(center, normal, feature, self.return_normal, self.return_polar)
+        else:
+            nc, nn_, nf = sample_and_group(self.npoint, self.radius, self.nsample, center, normal, feature,
+                                           self.return_normal, self.return_polar)
+        nf = nf.permute(0, 3, 2, 1)
+        x = F.relu(self.bn_l0(self.mlp_l0(nf[:, :self.pos_channel])) + self.bn_f0(self.mlp_f0(nf[:, self.pos_channel:])))
+        for conv, bn in zip(self.mlp_convs, self.mlp_bns):
+            x = F.relu(bn(conv(x)))
+        return nc.permute(0, 2, 1), nn_.permute(0, 2, 1), x.max(2)[0]
+
+
+class RepSurf2xModel(nn.Module):
+    """models/repsurf/repsurf_ssg_umb_2x.py:11-61."""
+
+    def __init__(self, args):
+        super().__init__()
+        cc = 0 if not args.return_center else (6 if args.return_polar else 3)
+        self.surface_constructor = UmbrellaSurfaceConstructor(args.group_size + 1, 10, return_dist=args.return_dist,
+                                                              aggr_type=args.umb_pool)
+        kw = dict(pos_channel=cc, return_polar=args.return_polar)
+        self.sa1 = SurfaceAbstractionCD(512, 0.1, 24, 10, mlp=[128, 128, 256], group_all=False, **kw)
+        self.sa2 = SurfaceAbstractionCD(128, 0.2, 24, 256 + 10, mlp=[256, 256, 512], group_all=False, **kw)
+        self.sa3 = SurfaceAbstractionCD(32, 0.4, 24, 512 + 10, mlp=[512, 512, 1024], group_all=False, **kw)
+        self.sa4 = SurfaceAbstractionCD(None, None, None, 1024 + 10, mlp=[1024, 1024, 2048], group_all=True, **kw)
+        self.classfier = nn.Sequential(nn.Linear(2048, 512), nn.BatchNorm1d(512), nn.ReLU(True), nn.Dropout(0.4),
+                                       nn.Linear(512, 256), nn.BatchNorm1d(256), nn.ReLU(True), nn.Dropout(0.4),
+                                       nn.Linear(256, args.num_class))
+
+    def forward(self, points):
+        center = points[:, :3, :]
+        normal = self.surface_constructor(center)
+        center, normal, feature = self.sa1(center, normal, None)
+        center, normal, feature = self.sa2(center, normal, feature)
+        center, normal, feature = self.sa3(center, normal, feature)
+        center, normal, feature = self.sa4(center, normal, feature)
+        return F.log_softmax(self.classfier(feature.view(-1, 2048)), -1)

@@ -278,6 +278,40 @@ def gen_umbrella():
     save("umbrella.npz", d)
 
 
+# ------------------------------------------------------------------ RepSurf baseline classifier (repsurf_ssg_umb_2x)
+def gen_repsurf2x():
+    import importlib
+    mod = importlib.import_module("models.repsurf.repsurf_ssg_umb_2x")
+    args = Namespace(return_center=True, return_polar=True, num_point=1024, return_dist=True, group_size=8,
+                     umb_pool="sum", cuda_ops=False, num_class=40)
+    d = {}
+    # (seed chosen so that no point has an exact tie at its 9th-nearest distance: which of two equidistant
+    #  neighbours torch.topk keeps is implementation-defined; seed 4242 has two such points)
+    pts = unit_cloud(2, 1024, seed=4243).transpose(1, 2).contiguous()
+    d["points"] = npy(pts)
+    model = fill_state(mod.Model(args), seed=21)
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    model.eval()
+    torch.manual_seed(5)
+    with torch.no_grad():
+        d["out_eval"] = npy(model(pts.clone()))
+    model.train()
+    torch.manual_seed(5)
+    out = model(pts.clone())
+    d["out_train"] = npy(out)
+    (out * randn(out.shape, seed=99)).sum().backward()
+    names = [n for n, p_ in model.named_parameters()]
+    d["grad_names"] = np.array(names)
+    d["grad_norms"] = np.array([float(p_.grad.double().norm()) if p_.grad is not None else 0.0
+                                for _, p_ in model.named_parameters()])
+    for n, p_ in model.named_parameters():
+        if n.startswith("surface_constructor") or n.startswith("classfier.8"):
+            d["grad." + n] = npy(p_.grad)
+    save("repsurf2x_model.npz", d)
+
+
 # ------------------------------------------------------------------ whole models
 def model_golden(model, run, params_full):
     """run(model) -> output tensor.  Returns eval output, train output, loss grads."""
@@ -388,9 +422,11 @@ def gen_seg():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["index", "blocks", "fuse", "sa", "umbrella", "cls", "seg"]
+    which = sys.argv[1:] or ["index", "blocks", "fuse", "sa", "umbrella", "repsurf2x", "cls", "seg"]
     if "umbrella" in which:
         gen_umbrella()
+    if "repsurf2x" in which:
+        gen_repsurf2x()
     if "sa" in which:
         gen_sa()
     if "index" in which:

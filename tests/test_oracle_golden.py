@@ -243,3 +243,25 @@ def test_ref_cpu_umbrella_front_end():
     m = fill_state(R.UmbrellaSurfaceConstructor(9, 10, aggr_type="sum", return_dist=True, random_inv=False), seed=13).eval()
     with torch.no_grad():
         assert np.abs(m(xyz.transpose(1, 2).clone()).numpy() - g["eval/out"]).max() < 1e-6 * np.abs(g["eval/out"]).max()
+
+
+def test_ref_cpu_repsurf_2x_model():
+    """The oracle's restatement of the RepSurf baseline classifier (models/repsurf/repsurf_ssg_umb_2x.py)
+    against outputs of the reference itself."""
+    from conftest import load_golden
+    g = load_golden("repsurf2x_model.npz")
+    args = Namespace(return_center=True, return_polar=True, num_point=1024, return_dist=True, group_size=8,
+                     umb_pool="sum", cuda_ops=False, num_class=40)
+    torch.set_num_threads(1)
+    m = fill_state(R.RepSurf2xModel(args), seed=21)
+    for mm in m.modules():
+        if isinstance(mm, torch.nn.Dropout):
+            mm.p = 0.0
+    pts = torch.from_numpy(g["points"])
+    m.eval()
+    torch.manual_seed(5)
+    with torch.no_grad():
+        assert np.abs(m(pts.clone()).numpy() - g["out_eval"]).max() < 1e-5
+    m.train()
+    torch.manual_seed(5)
+    assert np.abs(m(pts.clone()).detach().numpy() - g["out_train"]).max() < 1e-5
