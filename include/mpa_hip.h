@@ -213,9 +213,15 @@ int mpa_umbrella_features_f32(const float *xyz, const int64_t *knn_idx, int B, i
  * mean, over the coarse rows s that list fine point n, of points[s]; the divisor counts only
  * contributors whose channel-0 value is non-zero (0 -> 1), uncovered fine points stay 0
  * (the reference's quirks, :44-46).  The dense [B,S,Nf,C] tensor is never formed.
- * cnt [B,Nf] float (output, kept for backward).  out and cnt are zeroed by the callee. */
+ * cnt [B,Nf] float (output, kept for backward).  out and cnt are fully written by the callee.
+ * With a workspace of mpa_upsample_workspace_bytes() bytes (16-byte aligned device memory, scratch
+ * for the call) the forward is atomic-free: the neighbour table is inverted on the device and each
+ * fine point gathers its coarse rows.  workspace NULL / too small (or the size query returning 0:
+ * Nf beyond the inverter's per-cloud limit) selects the scatter path with float atomics. */
+size_t mpa_upsample_workspace_bytes(int B, int S, int K, int Nf);
 int mpa_upsample_mean_fwd_f32(const float *points, const int64_t *knn_idx, int B, int S, int K,
-                              int Nf, int C, float *out, float *cnt, void *stream);
+                              int Nf, int C, float *out, float *cnt, void *workspace,
+                              size_t workspace_bytes, void *stream);
 int mpa_upsample_mean_bwd_f32(const float *grad_out, const int64_t *knn_idx, const float *cnt,
                               int B, int S, int K, int Nf, int C, float *grad_points,
                               void *stream);

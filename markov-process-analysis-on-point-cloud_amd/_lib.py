@@ -50,7 +50,8 @@ SIGNATURES = {
     "mpa_bn_act_bwd_apply_f32": [_vp] * 7 + [_i, _f, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "mpa_scalar_add_f32": [_vp, _f, _vp],
     "mpa_adam_step_f32": [_vp, _vp, _vp, _vp, ctypes.c_longlong, _f, _f, _f, _f, _f, _vp, _vp],
-    "mpa_upsample_mean_fwd_f32": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp],
+    "mpa_upsample_workspace_bytes": [_i, _i, _i, _i],
+    "mpa_upsample_mean_fwd_f32": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, ctypes.c_size_t, _vp],
     "mpa_upsample_mean_bwd_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "mpa_three_interp_fwd_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "mpa_three_interp_bwd_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
@@ -69,6 +70,7 @@ for _name, _args in SIGNATURES.items():
     _fn.argtypes = _args
     _fn.restype = ctypes.c_int
 lib.mpa_diffattn_bwd_workspace_bytes.restype = ctypes.c_size_t
+lib.mpa_upsample_workspace_bytes.restype = ctypes.c_size_t
 lib.mpa_version.restype = ctypes.c_int
 lib.mpa_error_string.restype = ctypes.c_char_p
 lib.mpa_error_string.argtypes = [ctypes.c_int]

@@ -11,6 +11,7 @@
 // Backward uses the closed form of SURVEY.md Appendix A8 and recomputes the softmax; it keeps
 // only the 1-byte arg-max from forward.
 #include "mpa_common.h"
+#include "csr_build.h"
 
 namespace {
 
@@ -197,94 +198,6 @@ __global__ __launch_bounds__(TPB) void diffattn_bwd_kernel(const float *__restri
 // the chip's atomic rate (~0.9 TB/s); an LDS-resident accumulator per (cloud, channel slice)
 // was no faster: ds_add_f32 retires about one lane per 2.5 clocks.
 constexpr int BWD_TPB = 1024;
-
-// One workgroup per (cloud, range of base rows): it scans all S*K entries of the cloud, counts
-// those of its rows in LDS (integer LDS atomics are as slow as the float ones, so the rows are
-// split over CSR_RANGES workgroups per cloud), counts the entries below its range for the global
-// offset, scans, fills and sorts its rows' lists.
-constexpr int CSR_TPB = 256;
-
-__device__ __forceinline__ int block_exclusive_scan(int v, int *wave_tot, int &total)
-{
-    // inclusive scan inside the wave (DPP-free shuffles; 4 waves)
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    int x = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        int y = __shfl_up(x, off, 64);
-        if (lane >= off) x += y;
-    }
-    if (lane == 63) wave_tot[w] = x;
-    __syncthreads();
-    int base = 0;
-    total = 0;
-#pragma unroll
-    for (int i = 0; i < CSR_TPB / 64; ++i) {
-        if (i < w) base += wave_tot[i];
-        total += wave_tot[i];
-    }
-    __syncthreads();
-    return base + x - v;
-}
-
-__global__ __launch_bounds__(CSR_TPB) void csr_build_kernel(const int64_t *__restrict__ idx, int N, int SK, int range,
-                                                             int *__restrict__ rowptr, int *__restrict__ entries)
-{
-    extern __shared__ int csr_lds[];       // cnt[range] | pos[range]
-    __shared__ int wave_tot[CSR_TPB / 64];
-    constexpr int EPT = 32;                // entries per thread and chunk, all loads in flight at once
-    int *cnt = csr_lds, *pos = csr_lds + range;
-    const int b = blockIdx.y, tid = threadIdx.x;
-    const int r0 = blockIdx.x * range, r1 = min(N, r0 + range);
-    const int64_t *nb = idx + (size_t)b * SK;
-    int *rp = rowptr + (size_t)b * (N + 1);
-    int *en = entries + (size_t)b * SK;
-    for (int r = tid; r < range; r += CSR_TPB) cnt[r] = 0;
-    __syncthreads();
-    int rr[EPT];
-    const bool one_chunk = SK <= EPT * CSR_TPB;
-    int below = 0;
-    for (int base = 0; base < SK; base += EPT * CSR_TPB) {
-#pragma unroll
-        for (int u = 0; u < EPT; ++u) {
-            const int e = base + u * CSR_TPB + tid;
-            rr[u] = e < SK ? (int)mpa_clamp_idx(nb[e], N) : 0x7fffffff;
-        }
-#pragma unroll
-        for (int u = 0; u < EPT; ++u) {
-            below += rr[u] < r0;
-            if (rr[u] >= r0 && rr[u] < r1) atomicAdd(&cnt[rr[u] - r0], 1);
-        }
-    }
-    int nbelow;
-    block_exclusive_scan(below, wave_tot, nbelow);          // (syncs: cnt is complete afterwards)
-    // exclusive scan of cnt: thread t owns the contiguous chunk [t*per, (t+1)*per) of the range
-    const int per = (range + CSR_TPB - 1) / CSR_TPB;
-    int local = 0;
-    for (int r = tid * per; r < min(r1 - r0, (tid + 1) * per); ++r) local += cnt[r];
-    int tot;
-    int run = nbelow + block_exclusive_scan(local, wave_tot, tot);
-    for (int r = tid * per; r < min(r1 - r0, (tid + 1) * per); ++r) {
-        pos[r] = run;
-        rp[r0 + r] = run;
-        run += cnt[r];
-    }
-    if (r1 == N && tid == 0) rp[N] = SK;
-    __syncthreads();
-    // fill: entries of one row land in the order the LDS atomics retire (any order is a valid table)
-    for (int base = 0; base < SK; base += EPT * CSR_TPB) {
-        if (!one_chunk) {
-#pragma unroll
-            for (int u = 0; u < EPT; ++u) {
-                const int e = base + u * CSR_TPB + tid;
-                rr[u] = e < SK ? (int)mpa_clamp_idx(nb[e], N) : 0x7fffffff;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < EPT; ++u)
-            if (rr[u] >= r0 && rr[u] < r1) en[atomicAdd(&pos[rr[u] - r0], 1)] = base + u * CSR_TPB + tid;
-    }
-}
 
 template <int K_>
 __global__ __launch_bounds__(TPB) void diffattn_bwd_p1_kernel(
@@ -733,7 +646,6 @@ inline BwdWorkspace bwd_workspace(int B, int N, int S, int K, int C)
     w.total = w.entries_off + up((size_t)B * S * K * 4);
     return w;
 }
-constexpr int CSR_MAX_N = 12288;       // 2N ints of LDS <= 96 KB for a single row range
 }  // namespace
 
 extern "C" size_t mpa_diffattn_bwd_workspace_bytes(int B, int N, int S, int K, int C)
@@ -765,15 +677,7 @@ extern "C" int mpa_diffattn_bwd_f32(const float *q, int ldq, const float *k, con
         float *Tv = reinterpret_cast<float *>((char *)workspace + w.tv_off);
         int *rowptr = reinterpret_cast<int *>((char *)workspace + w.rowptr_off);
         int *entries = reinterpret_cast<int *>((char *)workspace + w.entries_off);
-        int ranges = 1;                                       // workgroups per cloud: ~256 rows each, >= 256 in all
-        while (ranges < 64 && (N / ranges > 256 || B * ranges < 256) && N / (2 * ranges) >= 32) ranges <<= 1;
-        const int range = (N + ranges - 1) / ranges;
-        static int attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&csr_build_kernel),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize,
-                                              2 * CSR_MAX_N * (int)sizeof(int));
-        (void)attr;
-        hipLaunchKernelGGL(csr_build_kernel, dim3(mpa_ceil_div(N, range), B), dim3(CSR_TPB),
-                           (size_t)2 * range * sizeof(int), st, idx, N, S * K, range, rowptr, entries);
+        launch_csr_build(idx, B, N, S * K, rowptr, entries, st);
         static const bool scalar_only = getenv("MPA_DIFFATTN_SCALAR") != nullptr;
         const bool p1v4 = !scalar_only && (C & 3) == 0 && (ldkv & 3) == 0 && (ldq & 3) == 0 &&
                           ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)grad_ctx | (uintptr_t)grad_q |

@@ -4,6 +4,8 @@
 // 1 KiB of contiguous row bytes per instruction; scatters use no-return float atomics on whole
 // rows (the shape that runs at the full atomic rate, MI355X guide "Global float atomics").
 #include "mpa_common.h"
+#include "csr_build.h"
+#include <cstdlib>
 
 namespace {
 
@@ -72,6 +74,59 @@ __global__ void upsample_divide_kernel(float *__restrict__ out, const float *__r
         float n = cnt[i / C];
         n = n == 0.0f ? 1.0f : n;
         out[i] = out[i] / n;
+    }
+}
+
+// upsample forward as a gather over the inverted neighbour table (csr_build.h): lane = (fine row n, V
+// channels) sums the coarse rows that list n (once per coarse row: scatter_ semantics), counts those
+// whose channel 0 is non-zero and divides -- no float atomics (B*S*K*C of them ran at the chip's atomic
+// rate: 70 us per call in the part-seg decoder), no clearing pass, no separate divide.
+template <int V>
+__global__ __launch_bounds__(TPB) void upsample_gather_kernel(const float *__restrict__ points,
+                                                              const int64_t *__restrict__ knn,
+                                                              const int *__restrict__ rowptr,
+                                                              const int *__restrict__ entries, int S, int K, int Nf,
+                                                              int C, int lanes_per_row, float *__restrict__ out,
+                                                              float *__restrict__ cnt)
+{
+    const int rl = threadIdx.x / lanes_per_row, cl = threadIdx.x % lanes_per_row;
+    const int rpb = TPB / lanes_per_row;
+    const int b = blockIdx.y;
+    const int n = blockIdx.x * rpb + rl;
+    if (n >= Nf) return;
+    const int *rp = rowptr + (size_t)b * (Nf + 1);
+    const int beg = rp[n], end = rp[n + 1];
+    const int *en = entries + (size_t)b * S * K;
+    const int64_t *kb = knn + (size_t)b * S * K;
+    const float *pb = points + (size_t)b * S * C;
+    for (int c = cl * V; c < C; c += lanes_per_row * V) {
+        float acc[V];
+#pragma unroll
+        for (int u = 0; u < V; ++u) acc[u] = 0.f;
+        float div = 0.f;
+        for (int e = beg; e < end; ++e) {
+            const int ent = en[e];
+            const int s = ent / K, k = ent - s * K;
+            bool dup = false;                       // the same fine row listed earlier by this coarse row
+            for (int j = 0; j < k; ++j) dup |= (mpa_clamp_idx(kb[(size_t)s * K + j], Nf) == n);
+            if (dup) continue;
+            const float *row = pb + (size_t)s * C;
+            if constexpr (V == 4) {
+                const float4 v = *reinterpret_cast<const float4 *>(row + c);
+                acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
+            } else {
+                acc[0] += row[c];
+            }
+            div += row[0] != 0.0f ? 1.f : 0.f;
+        }
+        if (c == 0) cnt[(size_t)b * Nf + n] = div;
+        const float d = div == 0.f ? 1.f : div;
+        float *o = out + ((size_t)b * Nf + n) * C + c;
+        if constexpr (V == 4) {
+            *reinterpret_cast<float4 *>(o) = make_float4(acc[0] / d, acc[1] / d, acc[2] / d, acc[3] / d);
+        } else {
+            o[0] = acc[0] / d;
+        }
     }
 }
 
@@ -197,12 +252,39 @@ extern "C" int mpa_gather_bwd_f32(const float *grad_out, const int64_t *idx, int
     return MPA_OK;
 }
 
+extern "C" size_t mpa_upsample_workspace_bytes(int B, int S, int K, int Nf)
+{
+    if (B <= 0 || S <= 0 || K <= 0 || Nf <= 0 || Nf > CSR_MAX_N || B > 65535 || (long long)S * K > 0x7fffffffLL) return 0;
+    return (((size_t)B * (Nf + 1) * 4 + 255) & ~(size_t)255) + (size_t)B * S * K * 4;
+}
+
 extern "C" int mpa_upsample_mean_fwd_f32(const float *points, const int64_t *knn_idx, int B, int S, int K, int Nf,
-                                         int C, float *out, float *cnt, void *stream)
+                                         int C, float *out, float *cnt, void *workspace, size_t workspace_bytes,
+                                         void *stream)
 {
     MPA_CLEAR_ERROR();
     if (!points || !knn_idx || !out || !cnt || B <= 0 || S <= 0 || K <= 0 || Nf <= 0 || C <= 0) return MPA_EINVAL;
     hipStream_t st = (hipStream_t)stream;
+    const size_t need = mpa_upsample_workspace_bytes(B, S, K, Nf);
+    static const bool force_atomic = getenv("MPA_UPSAMPLE_ATOMIC") != nullptr;
+    if (workspace && need && workspace_bytes >= need && ((uintptr_t)workspace & 15) == 0 && !force_atomic) {
+        int *rowptr = reinterpret_cast<int *>(workspace);
+        int *entries = reinterpret_cast<int *>((char *)workspace + (((size_t)B * (Nf + 1) * 4 + 255) & ~(size_t)255));
+        launch_csr_build(knn_idx, B, Nf, S * K, rowptr, entries, st);
+        const bool v4 = (C & 3) == 0 && ((((uintptr_t)points | (uintptr_t)out)) & 15) == 0;
+        const int per = v4 ? C / 4 : C;
+        int lanes = 1;
+        while (lanes < per && lanes < TPB) lanes <<= 1;
+        const dim3 grid(mpa_ceil_div(Nf, TPB / lanes), B);
+        if (v4)
+            hipLaunchKernelGGL(upsample_gather_kernel<4>, grid, dim3(TPB), 0, st, points, knn_idx, rowptr, entries, S, K,
+                               Nf, C, lanes, out, cnt);
+        else
+            hipLaunchKernelGGL(upsample_gather_kernel<1>, grid, dim3(TPB), 0, st, points, knn_idx, rowptr, entries, S, K,
+                               Nf, C, lanes, out, cnt);
+        MPA_LAUNCH_CHECK();
+        return MPA_OK;
+    }
     hipLaunchKernelGGL(clear_kernel, dim3(grid_for((long long)B * Nf * C)), dim3(TPB), 0, st, out, (long long)B * Nf * C,
                        cnt, (long long)B * Nf);
     long long total = (long long)B * S * K * C;

@@ -477,7 +477,10 @@ class _UpsampleMean(torch.autograd.Function):
         K = knn_idx.shape[2]
         out = torch.empty(B, n_fine, C, dtype=torch.float32, device=points.device)
         cnt = torch.empty(B, n_fine, dtype=torch.float32, device=points.device)
-        _launch("mpa_upsample_mean_fwd_f32", _p(points), _p(knn_idx), B, S, K, n_fine, C, _p(out), _p(cnt), _stream())
+        nbytes = int(lib.mpa_upsample_workspace_bytes(B, S, K, n_fine))      # 0: atomic scatter path
+        ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=points.device)
+        _launch("mpa_upsample_mean_fwd_f32", _p(points), _p(knn_idx), B, S, K, n_fine, C, _p(out), _p(cnt),
+                _p(ws) if nbytes else None, nbytes, _stream())
         ctx.save_for_backward(knn_idx, cnt)
         ctx.shape = (B, S, K, n_fine, C)
         return out
