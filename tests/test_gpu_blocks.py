@@ -531,3 +531,32 @@ def test_repsurf_2x_baseline_model():
         ref = float(g["grad_norms"][names.index(n)])
         got = float(p.grad.double().norm()) if p.grad is not None else 0.0
         assert abs(got - ref) <= 5e-2 * ref + 1e-5 * gmax, "%s: grad norm %g vs %g" % (n, got, ref)
+
+
+@pytest.mark.parametrize("B,S,K,r,C", [(2, 64, 8, 2, 20), (3, 100, 5, 4, 7), (1, 257, 16, 2, 128), (2, 33, 3, 2, 1)])
+def test_upsample_paths_match_oracle(B, S, K, r, C):
+    """Both forward paths of the C entry (gather over the inverted table with a workspace, float-atomic
+    scatter without) against the dense formulation, on neighbour lists with repeated fine points,
+    uncovered fine points and exact zeros in channel 0."""
+    import ctypes
+    from mpa_amd import _lib
+    from oracle import ref_cpu as R
+    gen = torch.Generator().manual_seed(B * 1000 + S)
+    pts = torch.randn(B, S, C, generator=gen)
+    pts[:, ::5, 0] = 0.0
+    idx = torch.randint(0, S * r, (B, S, K), generator=gen)
+    idx[:, :, 1] = idx[:, :, 0]                        # a coarse row listing a fine point twice
+    want = R.upsample(pts, idx, scale_ratio=r).numpy()
+    p, i = pts.cuda(), idx.cuda()
+    need = int(_lib.lib.mpa_upsample_workspace_bytes(B, S, K, S * r))
+    assert need > 0
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    for workspace in (ws, None):
+        out = torch.full((B, S * r, C), float("nan"), device="cuda")
+        cnt = torch.full((B, S * r), float("nan"), device="cuda")
+        rc = _lib.lib.mpa_upsample_mean_fwd_f32(p.data_ptr(), i.data_ptr(), B, S, K, S * r, C, out.data_ptr(),
+                                                cnt.data_ptr(), workspace.data_ptr() if workspace is not None else None,
+                                                need if workspace is not None else 0, None)
+        assert rc == 0
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-5, atol=1e-6)
