@@ -66,6 +66,7 @@ extern "C" int mpa_fps_f32(const float *xyz, int B, int N, int S, const int64_t 
     FPS_CASE(2048, 4, 8)
     FPS_CASE(4096, 16, 4)
     FPS_CASE(8192, 16, 8)
+    FPS_CASE(12288, 16, 12)     // 144 KB of LDS: ModelNet's 10000-point shapes (dataset/ModelNetDataLoader.py:47)
 #undef FPS_CASE
     return MPA_EUNSUPPORTED;
 }

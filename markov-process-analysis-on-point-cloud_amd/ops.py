@@ -149,6 +149,33 @@ def farthest_point_sample(xyz, npoint, cuda=False, start_idx=None, return_xyz=Fa
     return (out, oxyz) if return_xyz else out
 
 
+def farthest_point_sample_ragged(clouds, npoint, start_idx=None):
+    """FPS of clouds with DIFFERENT point counts in one launch: `clouds` is a list of [N_i, >=3] device
+    tensors -> (idx int64 [B, npoint], padded [B, Nmax, C]).  Every cloud is padded to the longest one
+    with copies of its point 0: a copy always carries point 0's running distance and a higher index,
+    so it never wins the arg-max -- row i equals farthest_point_sample(clouds[i][None], npoint) of the
+    reference, called one cloud at a time in list order (dataset/ShapeNetDataLoader.py:127-133),
+    including the repeated index 0 once a cloud is exhausted and the order the start indices are drawn
+    from the global CPU generator (one torch.randint(0, N_i, (1,)) per cloud)."""
+    _dev(*clouds)
+    B = len(clouds)
+    nmax = max(int(c.shape[0]) for c in clouds)
+    C = int(clouds[0].shape[1])
+    padded = torch.empty(B, nmax, C, dtype=torch.float32, device=clouds[0].device)
+    for i, c in enumerate(clouds):
+        n = int(c.shape[0])
+        padded[i, :n] = c
+        padded[i, n:] = c[0]
+    if start_idx is None:
+        start_idx = torch.cat([torch.randint(0, int(c.shape[0]), (1,), dtype=torch.long) for c in clouds])
+    start_idx = torch.as_tensor(start_idx, dtype=torch.long)
+    for i, c in enumerate(clouds):
+        if not 0 <= int(start_idx[i]) < int(c.shape[0]):
+            raise ValueError("farthest_point_sample_ragged: start_idx[%d] out of range" % i)
+    idx = farthest_point_sample(padded[:, :, :3].contiguous(), npoint, start_idx=start_idx)
+    return idx, padded
+
+
 def sample(nsample, feature, cuda=False):
     """Legacy helper the reference's train loop calls but never defines
     (tool/train_cls_scanobjectnn.py:244): FPS-downsample a channel-first batch

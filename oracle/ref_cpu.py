@@ -114,6 +114,33 @@ def three_interpolate(xyz1, xyz2, points2):
     return (index_points(points2, idx) * w.unsqueeze(-1)).sum(2)
 
 
+# ----------------------------------------------------------------------------- dataset readers (8f-4)
+def dataset_pc_normalize(pc):
+    """dataset/ModelNetDataLoader.py:12-17 == dataset/ShapeNetDataLoader.py:20-25 (numpy)."""
+    import numpy as np
+    pc = pc - np.mean(pc, axis=0)
+    return pc / np.max(np.sqrt(np.sum(pc ** 2, axis=1)))
+
+
+def dataset_farthest_point_sample(point, npoint, start):
+    """The ModelNet reader's own host-side FPS (dataset/ModelNetDataLoader.py:20-41), numpy, one shape:
+    fp32 squared distances kept in a float64 array, strict `<` update, first arg-max; `start` is the
+    value the reference draws with np.random.randint(0, N).  Returns the sampled rows [npoint, D]."""
+    import numpy as np
+    N, D = point.shape
+    xyz = point[:, :3]
+    chosen = np.zeros((npoint,), dtype=np.int64)
+    distance = np.ones((N,)) * 1e10
+    farthest = int(start)
+    for i in range(npoint):
+        chosen[i] = farthest
+        dist = np.sum((xyz - xyz[farthest, :]) ** 2, -1)
+        closer = dist < distance
+        distance[closer] = dist[closer]
+        farthest = int(np.argmax(distance, -1))
+    return point[chosen]
+
+
 # ----------------------------------------------------------------------------- L1 blocks
 class Linear(nn.Module):
     def __init__(self, in_channels, out_channels, bn=True, act=True):
