@@ -57,7 +57,8 @@ extern "C" int mpa_fps_f32(const float *xyz, int B, int N, int S, const int64_t 
     if (N <= (MAXN)) return launch<W, P>(xyz, B, N, S, start_idx, out_idx, out_xyz, st);
     // (waves, points per lane) by measurement: an iteration costs ~0.36-0.45 us whatever the split --
     // it is the chain LDS read -> update -> DPP arg-max -> LDS slot -> barrier -> LDS read -- and a
-    // single wave (no barrier) wins up to N = 512; 16 waves were 1.8x slower at N = 1024.
+    // single wave (no barrier) wins up to N = 512; at N = 1024 two waves cost 0.42, four 0.39, eight 0.60
+    // and sixteen 0.70 us per iteration (the barrier gets expensive beyond one wave per SIMD).
     FPS_CASE(64, 1, 1)
     FPS_CASE(128, 1, 2)
     FPS_CASE(256, 1, 4)

@@ -13,7 +13,12 @@ __device__ __forceinline__ void fps_body(const float *__restrict__ xyz, int N, i
     constexpr int T = WAVES * 64;
     constexpr int NP = T * P;
     float *sx = lds, *sy = lds + NP, *sz = lds + 2 * NP;
-    uint2 *slot = reinterpret_cast<uint2 *>(lds + 3 * NP);   // [2][WAVES]
+    // [2][WAVES] wave winners as ONE 64-bit key each: distance bits << 32 | ~index.  The largest key is the
+    // largest distance and, among equal distances, the lowest index, so the waves are combined with
+    // plain 64-bit maxima of one b64 read per slot (a (distance, index) pair made the compiler read
+    // the distances, pick, and go back to LDS for the winner's index: one more dependent round trip
+    // per iteration).
+    unsigned long long *slot = reinterpret_cast<unsigned long long *>(lds + 3 * NP);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -68,15 +73,15 @@ __device__ __forceinline__ void fps_body(const float *__restrict__ xyz, int N, i
         if (WAVES == 1) {
             far = widx;
         } else {
-            if (lane == 0) slot[par * WAVES + wave] = make_uint2(wmax, (unsigned)widx);
+            if (lane == 0) slot[par * WAVES + wave] = ((unsigned long long)wmax << 32) | (unsigned)~widx;
             __syncthreads();
-            uint2 bst = slot[par * WAVES];
+            unsigned long long bst = slot[par * WAVES];
 #pragma unroll
             for (int w = 1; w < WAVES; ++w) {
-                uint2 s = slot[par * WAVES + w];
-                if (s.x > bst.x) bst = s;
+                const unsigned long long s = slot[par * WAVES + w];
+                bst = s > bst ? s : bst;
             }
-            far = (int)bst.y;
+            far = (int)~(unsigned)bst;
             par ^= 1;
         }
     }
