@@ -674,7 +674,12 @@ int launch_knn_mfma(const float *base, const float *query, int B, int N, int S, 
                             sizeof(float);
     constexpr size_t merge = (size_t)32 * 2 * WAVES * KMAX * 8;
     constexpr size_t lds = work > merge ? work : merge;
-    static_assert(lds <= 64 * 1024, "stay under the default dynamic LDS limit");
+    static_assert(lds <= 160 * 1024, "LDS of a gfx950 CU");
+    if (lds > 64 * 1024) {
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_mfma_kernel<CT, WAVES, KMAX>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (attr != hipSuccess) return MPA_EHIP;
+    }
     dim3 grid(mpa_ceil_div(S, 32), B);
     hipLaunchKernelGGL((knn_mfma_kernel<CT, WAVES, KMAX>), grid, dim3(WAVES * 64), lds, st, base, query, N, S, K, od,
                        oi);
@@ -768,8 +773,10 @@ extern "C" int mpa_knn_f32(const float *base, const float *query, int B, int N, 
         case 3: return launch_knn_mfma_k<3, 4>(base, query, B, N, S, K, out_dist, out_idx, st);
         case 32: return launch_knn_mfma_k<32, 4>(base, query, B, N, S, K, out_dist, out_idx, st);
         case 64: return launch_knn_mfma_k<64, 4>(base, query, B, N, S, K, out_dist, out_idx, st);
-        case 128: return launch_knn_mfma_k<128, 2>(base, query, B, N, S, K, out_dist, out_idx, st);
-        case 256: return launch_knn_mfma_k<256, 1>(base, query, B, N, S, K, out_dist, out_idx, st);
+        // wide rows: the few (S/32)*B workgroups are latency bound on staging their base tiles, so the
+        // tiles are dealt to more waves (one 33 KB / 17 KB slab each: past the 64 KB default)
+        case 128: return launch_knn_mfma_k<128, 4>(base, query, B, N, S, K, out_dist, out_idx, st);
+        case 256: return launch_knn_mfma_k<256, 2>(base, query, B, N, S, K, out_dist, out_idx, st);
         default: break;
         }
     }
