@@ -518,14 +518,12 @@ __global__ __launch_bounds__(BWD_TPB) void diffattn_xyz_bwd_kernel(
     float alpha, long long npoints, float *__restrict__ gWq, float *__restrict__ gbq, float *__restrict__ gWk,
     float *__restrict__ gbk, float *__restrict__ gWv, float *__restrict__ gbv)
 {
-    __shared__ float red[12][256];
+    __shared__ float red[12 * BWD_TPB];              // [PW][12][bx]: one row of partial sums per point lane
     const int k_ = K_ > 0 ? K_ : K;
     const int cl = threadIdx.x % bx, pw = threadIdx.x / bx, PW = blockDim.x / bx;
     const int c = blockIdx.y * bx + cl;
     const bool live = c < C;
     const int cc = live ? c : C - 1;
-    for (int i = threadIdx.x; i < 12 * 256; i += blockDim.x) (&red[0][0])[i] = 0.f;
-    __syncthreads();
     const float wq0 = Wq[cc * 3], wq1 = Wq[cc * 3 + 1], wq2 = Wq[cc * 3 + 2], bqc = bq[cc];
     const float wk0 = Wk[cc * 3], wk1 = Wk[cc * 3 + 1], wk2 = Wk[cc * 3 + 2], bkc = bk[cc];
     const float wv0 = Wv[cc * 3], wv1 = Wv[cc * 3 + 1], wv2 = Wv[cc * 3 + 2], bvc = bv[cc];
@@ -575,23 +573,28 @@ __global__ __launch_bounds__(BWD_TPB) void diffattn_xyz_bwd_kernel(
         const float dv = g * (astar - o);
         av[0] = fmaf(dv, sx, av[0]); av[1] = fmaf(dv, sy, av[1]); av[2] = fmaf(dv, sz, av[2]); av[3] += dv;
     }
+    // block reduction over the PW point lanes through LDS with plain stores (LDS float atomics retire
+    // ~1 lane per 2.5 clocks: 12 of them per thread were a quarter of this kernel), then one global
+    // atomic per (parameter, channel) and block
+    float *mine = red + (size_t)pw * 12 * bx + cl;
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
-        atomicAdd(&red[d][cl], aq[d]);
-        atomicAdd(&red[4 + d][cl], ak[d]);
-        atomicAdd(&red[8 + d][cl], av[d]);
+        mine[d * bx] = aq[d];
+        mine[(4 + d) * bx] = ak[d];
+        mine[(8 + d) * bx] = av[d];
     }
     __syncthreads();
-    if (pw == 0 && live) {
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            atomicAdd(gWq + c * 3 + d, red[d][cl]);
-            atomicAdd(gWk + c * 3 + d, red[4 + d][cl]);
-            atomicAdd(gWv + c * 3 + d, red[8 + d][cl]);
-        }
-        atomicAdd(gbq + c, red[3][cl]);
-        atomicAdd(gbk + c, red[7][cl]);
-        atomicAdd(gbv + c, red[11][cl]);
+    for (int t = threadIdx.x; t < 12 * bx; t += blockDim.x) {
+        const int d = t / bx, l = t - d * bx;
+        const int ch = blockIdx.y * bx + l;
+        if (ch >= C) continue;
+        float sum = 0.f;
+        for (int w = 0; w < PW; ++w) sum += red[(size_t)w * 12 * bx + t];
+        const int which = d >> 2, comp = d & 3;                 // (q, k, v) x (dW[0..2], db)
+        float *gw = which == 0 ? gWq : (which == 1 ? gWk : gWv);
+        float *gb = which == 0 ? gbq : (which == 1 ? gbk : gbv);
+        if (comp < 3) atomicAdd(gw + ch * 3 + comp, sum);
+        else atomicAdd(gb + ch, sum);
     }
 }
 
