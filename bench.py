@@ -191,7 +191,7 @@ def main():
         clouds = a.batch * world * a.steps
         traffic = {}
         try:        # HBM bytes per launch from the committed rocprofv3 PMC passes (see the file's "how")
-            with open(os.path.join(ROOT, "profiles", "r01e_pmc_traffic.json")) as fh:
+            with open(os.path.join(ROOT, "profiles", "r01f_pmc_traffic.json")) as fh:
                 traffic = {k: v.get("hbm_bytes_per_launch") for k, v in json.load(fh)["kernels"].items()}
         except (OSError, ValueError, KeyError):
             pass
