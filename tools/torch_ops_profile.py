@@ -21,13 +21,14 @@ def step():
 for _ in range(3): step()
 torch.cuda.synchronize()
 from torch.profiler import profile, ProfilerActivity
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof:
     step(); torch.cuda.synchronize()
 rows = []
-for e in prof.key_averages(group_by_input_shape=True):
+for e in prof.key_averages(group_by_input_shape=True, group_by_stack_n=12):
     dt = getattr(e, "device_time_total", None) or getattr(e, "cuda_time_total", 0)
     if dt > 0 and e.key.startswith("aten::"):
-        rows.append((dt, e.count, e.key, str(e.input_shapes)))
+        where = [f for f in e.stack if "mpa" in f or "markov" in f]
+        rows.append((dt, e.count, e.key, str(e.input_shapes)[:70], " <- ".join(w.split("/")[-1][:60] for w in where[:3])))
 rows.sort(reverse=True)
-for dt, cnt, key, shp in rows[:70]:
-    print("%9.1f us %5d calls  %-22s %s" % (dt, cnt, key, shp[:110]))
+for dt, cnt, key, shp, where in rows[:60]:
+    print("%8.1f us %4d  %-18s %-70s %s" % (dt, cnt, key, shp, where))
