@@ -520,7 +520,9 @@ __global__ __launch_bounds__(BWD_TPB) void diffattn_xyz_bwd_kernel(
 {
     __shared__ float red[12 * BWD_TPB];              // [PW][12][bx]: one row of partial sums per point lane
     const int k_ = K_ > 0 ? K_ : K;
-    const int cl = threadIdx.x % bx, pw = threadIdx.x / bx, PW = blockDim.x / bx;
+    // bx is a multiple of 64, so a wave shares its point lane: telling the compiler (readfirstlane) turns the
+    // point's centre / neighbour-index / coordinate loads (35 per point) into scalar loads
+    const int cl = threadIdx.x % bx, pw = __builtin_amdgcn_readfirstlane(threadIdx.x / bx), PW = blockDim.x / bx;
     const int c = blockIdx.y * bx + cl;
     const bool live = c < C;
     const int cc = live ? c : C - 1;
