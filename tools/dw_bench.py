@@ -64,3 +64,30 @@ us = e0.elapsed_time(e1) / n * 1e3
 print("grouped dW: %.1f us  (%.2f TB/s unique, %.1f TFLOP/s)  stream=%s wgs=%s kchunk=%s" % (
     us, tot_b / us / 1e6, tot_f / us / 1e6, os.environ.get("MPA_TN_STREAM", "1"), os.environ.get("MPA_TN_WGS", "512"),
     os.environ.get("MPA_TN_KCHUNK", "256")))
+if "-p" in os.environ.get("DW_ARGS", ""):
+    # every product as a grouped launch of its own: where does the launch's time go?
+    import collections
+    agg = collections.OrderedDict()
+    for q in saved:
+        key = (q[5], q[6], q[7])
+        if key in agg:
+            agg[key][0] += 1
+            continue
+        for _ in range(2):
+            ops._DW_QUEUE.append(q)
+            ops.flush_weight_grads()
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(10):
+            ops._DW_QUEUE.append(q)
+            ops.flush_weight_grads()
+        e1.record()
+        torch.cuda.synchronize()
+        agg[key] = [1, e0.elapsed_time(e1) / 10 * 1e3]
+    tot = 0.0
+    for (M, N, K), (cnt, t) in sorted(agg.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
+        fl, by = 2.0 * M * N * K, 4.0 * K * (M + N)
+        tot += cnt * t
+        print("  M=%5d N=%5d K=%6d x%d : %7.1f us alone  %6.1f TFLOP/s %5.2f TB/s   (%.0f us if run one by one)" % (
+            M, N, K, cnt, t, fl / t / 1e6, by / t / 1e6, cnt * t))
+    print("sum of the products run one by one: %.0f us" % tot)
