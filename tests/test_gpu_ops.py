@@ -366,3 +366,32 @@ def test_fused_fps_knn_xyz_equals_separate_launches(ops, B, fN, fS, N, S):
     dist0, idx0 = ops.knn_point(8, base, query)
     assert torch.equal(fidx, fidx0) and torch.equal(fxyz, fxyz0)
     assert torch.equal(idx, idx0) and torch.equal(bits(dist.cpu().numpy()) if False else dist, dist0)
+
+
+# --------------------------------------------------------------------------- grouped weight gradients
+def test_grouped_weight_gradients_vs_torch(ops):
+    """mpa_gemm_tn_grouped_f32 through ops' queue: out_p = A_p^T B_p (+ column sums of A_p) for a mix of
+    products -- 128 x 128-tile ones (M, N multiples of 128; split over K and not), 64 x 64-tile ones,
+    streamed single-tile ones, ragged ones -- against torch in float64."""
+    g = torch.Generator().manual_seed(77)
+    shapes = [(512, 256, 4096), (256, 128, 8192), (128, 128, 512), (1024, 512, 2048), (128, 256, 300), (64, 64, 16384),
+              (128, 64, 4096), (40, 256, 64), (64, 3, 8192), (256, 384, 1024)]
+    queue, want = [], []
+    for M, N, K in shapes:
+        gy = (torch.randint(-4, 5, (K, M), generator=g).float() * 0.25).cuda()
+        x = (torch.randint(-4, 5, (K, N), generator=g).float() * 0.5).cuda()
+        out = torch.full((M, N), float("nan"), device="cuda")
+        acs = torch.zeros(M, device="cuda")
+        queue.append((gy, M, x, N, out, M, N, K, acs))
+        want.append((gy.double().t() @ x.double(), gy.double().sum(0)))
+    ops.defer_weight_grads(True)
+    try:
+        ops._DW_QUEUE.extend(queue)
+        ops.flush_weight_grads()
+    finally:
+        ops.defer_weight_grads(False)
+    torch.cuda.synchronize()
+    for (M, N, K), q, (w, ws) in zip(shapes, queue, want):
+        # operands are multiples of 1/4 and 1/2 with small magnitudes: every partial sum is exact in fp32
+        assert torch.equal(q[4].double(), w), (M, N, K)
+        assert torch.equal(q[8].double(), ws), (M, N, K)
