@@ -44,7 +44,8 @@ const char *mpa_last_hip_error_string(void);
  * torch.randint on the CPU generator, :96 -- the host wrapper does the same and passes it in).
  * out_idx [B,S] int64; out_xyz [B,S,3] (optional, may be NULL) receives xyz[out_idx], i.e.
  * the index_points() call that follows every FPS in the models (repsurface_utils.py:583).
- * Distances follow the reference's rounding exactly (no FMA contraction), ties -> first max. */
+ * Distances follow the reference's rounding exactly (no FMA contraction), ties -> first max.
+ * One workgroup per cloud with the cloud resident on chip: N <= 12288 (MPA_EUNSUPPORTED beyond). */
 int mpa_fps_f32(const float *xyz, int B, int N, int S, const int64_t *start_idx,
                 int64_t *out_idx, float *out_xyz, void *stream);
 
