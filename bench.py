@@ -13,7 +13,9 @@ per-GPU batch fixed).  Inputs are resident in HBM before the timed region.
 
 Rank 0 prints ONE JSON line.  Extra objects: "roofline" for the dominant kernel (HIP events on
 the launch stream around that kernel's launches inside the timed region), "cpu_baseline" (the
-CPU oracle oracle/ref_cpu.py timed on this box's host cores on a bounded sample; rank 0, N=1).
+CPU oracle oracle/ref_cpu.py timed on this box's host cores on a bounded sample; rank 0, N=1;
+its "forward_only_value" is the same model's forward pass alone) and, at N=1, "forward_only" (the
+forward pass alone as a HIP graph, measured after the timed region: a secondary figure).
 """
 import argparse
 import json
@@ -71,6 +73,35 @@ def log(msg):
     print("[bench] " + msg, file=sys.stderr, flush=True)
 
 
+def forward_only(model, x, feeder, iters=50):
+    """Forward pass alone (train-mode BatchNorm statistics, no autograd), captured as a HIP graph: a
+    secondary figure next to the headline fwd+bwd metric (SURVEY 8d states the >= 20x target on it)."""
+    with torch.no_grad():
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                feeder.begin_pass()
+                model(x)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            feeder.begin_pass()
+            model(x)
+        for _ in range(5):
+            feeder.refill()
+            g.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            feeder.refill()
+            g.replay()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / iters
+    return {"value": x.shape[0] / dt, "unit": "point-clouds/s", "ms_per_step": dt * 1e3, "steps": iters}
+
+
 def cpu_baseline(batch, steps=3):
     """The oracle's plain-PyTorch restatement of the reference path, fwd+bwd+Adam on host cores."""
     from oracle import ref_cpu as R
@@ -93,9 +124,18 @@ def cpu_baseline(batch, steps=3):
         log("cpu baseline step %d: %.2f s" % (i, times[-1]))
     times = sorted(times[1:])
     med = times[len(times) // 2]
+    ftimes = []
+    with torch.no_grad():                                  # forward only (the >= 20x target is on forward)
+        for i in range(steps + 1):
+            t0 = time.perf_counter()
+            model(x)
+            ftimes.append(time.perf_counter() - t0)
+    fmed = sorted(ftimes[1:])[len(ftimes[1:]) // 2]
+    log("cpu baseline forward only: %.2f s" % fmed)
     return {"value": batch / med, "unit": "point-clouds/s", "cores": threads, "kind": "port",
             "sample": "oracle/ref_cpu.py ClsModel fwd+bwd+Adam, batch %d x %d pts, 1 warm-up + %d timed steps, median"
-                      % (batch, NUM_POINT, steps)}
+                      % (batch, NUM_POINT, steps),
+            "forward_only_value": batch / fmed}
 
 
 def main():
@@ -229,6 +269,8 @@ def main():
             "roofline": roof,
             "roofline_other_kernels": kernels[1:],
         }
+        if world == 1 and not a.eager:
+            line["forward_only"] = forward_only(model, x, graphed.feeder)
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.batch)
         print(json.dumps(line), flush=True)

@@ -11,7 +11,7 @@ from mpa_amd import ops
 from mpa_amd.models.repsurf.repsurf_ssg_umb import Model
 from kbench import timeit
 sys.argv = [sys.argv[0]]
-from bench import synthetic_batch, host_cores
+from bench import synthetic_batch
 
 dev = torch.device("cuda")
 # HBM copy: 1 GiB device-to-device (read + write bytes counted)
@@ -53,13 +53,4 @@ with torch.no_grad():
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 50
 print("cls forward only (B=64, N=1024, fp32, HIP graph): %.3f ms -> %.0f clouds/s" % (dt * 1e3, 64 / dt))
 ops.set_fps_start_hook(None)
-# CPU forward baseline (oracle restatement)
-from oracle import ref_cpu as R
-torch.set_num_threads(host_cores())
-cm = R.ClsModel(argparse.Namespace(num_point=1024, return_dist=True, cuda_ops=False, num_class=40)).train()
-xc, _ = synthetic_batch(64, 1234, "cpu")
-with torch.no_grad():
-    cm(xc); ts = []
-    for _ in range(3):
-        t0 = time.perf_counter(); cm(xc); ts.append(time.perf_counter() - t0)
-print("CPU forward (oracle/ref_cpu.py, %d threads, B=64): %.2f s -> %.1f clouds/s" % (host_cores(), sorted(ts)[1], 64 / sorted(ts)[1]))
+# (the CPU forward baseline is measured by bench.py's cpu_baseline leg: "forward_only_value")
