@@ -3,9 +3,13 @@ nn.Module classes, constructor signatures and state-dict keys, with the device w
 the gfx950 kernels of libmpa_hip.so (see ../ops.py).
 
 Reference locations (Markov_Process_Analysis_on_Point_Cloud/modules/pointnet2_utils.py):
-  upsample:13  index_points:64  farthest_point_sample:84  query_ball_point:112
-  sample_and_group:137  square_distance:190  knn_point:211  Linear:401  LocalMerge:427
-  LocalTrans:479  Fuse:576  KeepHighResolutionModulePartSeg:711  PointNetFeaturePropagation:860
+  upsample:13  mod_index:53  index_points:64  farthest_point_sample:84  query_ball_point:112
+  sample_and_group:137  sample_and_group_all:168  square_distance:190  knn_point:211  knn_point2:224
+  random_sample:253  convert_polar:263  resort_points:289  group_by_umbrella:309
+  UmbrellaSurfaceConstructor:333  Linear:401  LocalMerge:427  LocalTrans:479  Fuse:576
+  KeepHighResolutionModulePartSeg:711  PointNetFeaturePropagation:860
+Every public name of the reference file exists here, so the reference's own model files import over
+this module unchanged (tests/test_cabi_cpu.py runs that recipe).
 """
 import torch
 import torch.nn as nn
@@ -14,6 +18,116 @@ import torch.nn.functional as F
 from .. import ops
 from ..ops import (farthest_point_sample, index_points, knn_point, query_ball_point, query_knn_point,  # noqa: F401
                    sample, square_distance, three_interpolate, three_nn, upsample)
+
+
+def mod_index(bse_xyz, mod_idx, xyz):
+    """reference :53-61 -- rows mod_idx[b] of bse_xyz [B,N,D] replaced by xyz [B,M,D]."""
+    out = bse_xyz.clone()
+    bidx = torch.arange(mod_idx.shape[0], device=bse_xyz.device).unsqueeze(-1).expand_as(mod_idx)
+    out[bidx.reshape(-1), mod_idx.reshape(-1), :] = xyz.reshape(-1, xyz.shape[-1]).to(out.dtype)
+    return out
+
+
+def sample_and_group_all(xyz, points):
+    """reference :168-186 -- the whole cloud as one group around the origin."""
+    B, N, C = xyz.shape
+    new_xyz = torch.zeros(B, 1, C, device=xyz.device)
+    grouped_xyz = xyz.view(B, 1, N, C)
+    if points is not None:
+        return new_xyz, torch.cat([grouped_xyz, points.view(B, 1, N, -1)], dim=-1)
+    return new_xyz, grouped_xyz
+
+
+def knn_point2(nsample, xyz, new_xyz):
+    """reference :224-251 (unused by the models): top-k of the distance matrix with exact zeros
+    replaced by 10 + N(0,1) noise and the diagonal zeroed.  The noise comes from the device generator,
+    so results are random where zeros occur (parity unpinned by construction)."""
+    sq = square_distance(new_xyz, xyz)
+    B, N, _ = sq.shape
+    noise = torch.randn(sq.shape, device=sq.device)
+    sq = torch.where(sq == 0, 10 + noise, sq)
+    off_diag = 1.0 - torch.eye(N, sq.shape[2], device=sq.device).unsqueeze(0)
+    return torch.topk(sq * off_diag, nsample, dim=-1, largest=False, sorted=True)
+
+
+def random_sample(xyz, sample_num):
+    """reference :253-261 -- one random permutation (CPU generator) shared by the whole batch."""
+    B, N, _ = xyz.shape
+    perm = torch.randperm(N)
+    idx = perm[:sample_num].to(xyz.device)
+    return xyz[:, idx, :], idx.unsqueeze(0).expand(B, sample_num)
+
+
+def convert_polar(neighbours, center):
+    """reference :263-287 -- axis-wise polar angles of [B,3,S,K] neighbour offsets (keeps the
+    reference's r_yz = sqrt(y^2 + y^2))."""
+    rel = (neighbours - center).permute(0, 2, 3, 1).contiguous()
+    x, y, z = rel[..., 0], rel[..., 1], rel[..., 2]
+    r_xy, r_zx, r_yz = torch.sqrt(x ** 2 + y ** 2), torch.sqrt(z ** 2 + x ** 2), torch.sqrt(y ** 2 + y ** 2)
+    u = lambda t: t.unsqueeze(-3).contiguous()
+    z_beta, z_alpha = u(torch.atan2(z, r_xy)), u(torch.atan2(y, x))
+    y_beta, y_alpha = u(torch.atan2(y, r_zx)), u(torch.atan2(x, z))
+    x_beta, x_alpha = u(torch.atan2(x, r_yz)), u(torch.atan2(z, y))
+    return x_alpha, x_beta, y_alpha, y_beta, z_alpha, z_beta
+
+
+def resort_points(points, idx):
+    """reference :289-307 -- points [B,N,G,C] re-ordered along G by idx [B,N,G]."""
+    return torch.gather(points, 2, idx.unsqueeze(-1).expand(-1, -1, -1, points.shape[-1]))
+
+
+def group_by_umbrella(xyz, new_xyz, k=9, cuda=False):
+    """reference :309-331 (== repsurface_utils.py:106-126).  [B,N',k-1,3 (centre, p_i, p_i+1),3]: the
+    k-1 nearest neighbours of each point of new_xyz (the nearest dropped), relative to it, sorted by
+    azimuth, paired cyclically."""
+    from .polar_utils import xyz2sphere
+    idx = query_knn_point(k, xyz, new_xyz)
+    rel = index_points(xyz, idx)[:, :, 1:] - new_xyz.unsqueeze(-2)
+    order = xyz2sphere(rel)[..., 2].argsort(dim=-1, stable=True)
+    srt = resort_points(rel, order).unsqueeze(-2)
+    return torch.cat([torch.zeros_like(srt), srt, torch.roll(srt, -1, dims=-3)], dim=-2)
+
+
+class UmbrellaSurfaceConstructor(nn.Module):
+    """Umbrella-based surface abstraction (reference :333-399 == repsurface_utils.py:321-376): per
+    point the k-1 triangles around it -> (centre | polar | normal | position) -> three 1x1 convolutions
+    (BatchNorm + ReLU after the first two) -> sum / mean / max over the triangles.  [B,3,N] ->
+    [B,in_channel,N].  The triangle features come from one fused kernel (ops.umbrella_features), the
+    convolutions run as the MFMA Linear unit over the B*N*(k-1) rows; parameter names equal the
+    reference's."""
+
+    def __init__(self, k, in_channel, aggr_type='sum', return_dist=False, random_inv=True, cuda=False):
+        super().__init__()
+        self.k = k
+        self.return_dist = return_dist
+        self.random_inv = random_inv
+        self.aggr_type = aggr_type
+        self.cuda_ops = cuda      # the reference stores this as `self.cuda`, shadowing nn.Module.cuda
+        self.mlps = nn.Sequential(
+            nn.Conv2d(in_channel, in_channel, 1, bias=False), nn.BatchNorm2d(in_channel), nn.ReLU(True),
+            nn.Conv2d(in_channel, in_channel, 1, bias=True), nn.BatchNorm2d(in_channel), nn.ReLU(True),
+            nn.Conv2d(in_channel, in_channel, 1, bias=True))
+
+    def forward(self, center):
+        center = center.permute(0, 2, 1).contiguous()
+        B, N, _ = center.shape
+        sign = None
+        if self.random_inv:       # per-cloud flip drawn from the CPU generator, as the reference does
+            sign = torch.randint(0, 2, (B, 1, 1)).float().view(B) * 2. - 1.
+        f = ops.umbrella_features(center, self.k, cloud_sign=sign, return_dist=self.return_dist)   # [B,N,G,CH]
+        G, CH = f.shape[2], f.shape[3]
+        m = self.mlps
+        x = f.view(B, N * G, CH)
+        x = ops.linear_bn_act(x, m[0].weight.view(CH, CH), None, m[1], 0.0)
+        x = ops.linear_bn_act(x, m[3].weight.view(CH, CH), m[3].bias, m[4], 0.0)
+        x = ops.linear(x, m[6].weight.view(CH, CH), m[6].bias).view(B, N, G, CH)
+        if self.aggr_type == 'max':
+            x = x.max(dim=2)[0]
+        elif self.aggr_type == 'avg':
+            x = x.mean(dim=2)
+        else:
+            x = x.sum(dim=2)
+        return x.permute(0, 2, 1)
 
 
 def sample_and_group(npoint, radius, nsample, xyz, points, returnfps=False):
@@ -87,10 +201,10 @@ class LocalTrans(nn.Module):
     def forward(self, features, idx, pos, FPS_idx=None, xyz=False, center=None):
         # `center` (optional, not in the reference signature): index_points(features, FPS_idx) when
         # the caller already has it (LocalMerge gathers it once for both feature streams and the kNN)
-        if self.usetanh:
-            raise NotImplementedError("usetanh=True is dead code in the reference models (always False)")
         if center is None:
             center = index_points(features, FPS_idx) if FPS_idx is not None else features
+        if self.usetanh:
+            return self.finish(self._tanh_context(features, idx, center, xyz), center)
         if xyz:
             context = ops.diffattn_xyz(features, center, idx, self.q.weight, self.q.bias, self.k.weight,
                                        self.k.bias, self.v.weight, self.v.bias)
@@ -100,6 +214,21 @@ class LocalTrans(nn.Module):
             kv = ops.linear_kv(features, self.k, self.v)
             context = ops.diffattn(q, kv, idx)
         return self.finish(context, center)
+
+    def _tanh_context(self, features, idx, center, xyz):
+        """`usetanh=True` (reference :535-537, :560-562; never enabled by the models): attention =
+        tanh(q - k) / patchNum, context = matmul(attention, value).squeeze(-2) exactly as written there --
+        a [K,C] x [K,C] product, so like the reference it only runs when C == K."""
+        q = ops.linear(center, self.q.weight, self.q.bias).unsqueeze(-2)
+        if xyz:
+            rel = index_points(features, idx) - center.unsqueeze(-2)
+            key = ops.linear(rel, self.k.weight, self.k.bias)
+            val = ops.linear(rel, self.v.weight, self.v.bias)
+        else:
+            key = index_points(ops.linear(features, self.k.weight, self.k.bias), idx)
+            val = index_points(ops.linear(features, self.v.weight, self.v.bias), idx)
+        attention = torch.tanh(q - key) / self.patchNum
+        return torch.matmul(attention, val).squeeze(-2)
 
     def finish(self, context, center):
         """out = res + Linear_ffn(context), res = conv_res(centre) if `residual` else the centre."""
@@ -120,7 +249,7 @@ def local_trans_pair(t1, t2, features, idx1, idx2, center):
     are one GEMM over the base rows, the two query projections one GEMM over the centres, and the
     attention backward hands each stacked projection a single gradient."""
     if t1.usetanh or t2.usetanh:
-        raise NotImplementedError("usetanh=True is dead code in the reference models (always False)")
+        return t1(features, idx1, None, center=center), t2(features, idx2, None, center=center)
     qq = ops.linear_stack(center, (t1.q, t2.q), (True, True))
     kvkv = ops.linear_stack(features, (t1.k, t1.v, t2.k, t2.v), (True, False, True, False))
     c1, c2 = ops.diffattn_pair(qq, kvkv, idx1, idx2)

@@ -4,7 +4,8 @@ same names, signatures and state-dict keys; device work in libmpa_hip.so.
 Reference locations (Markov_Process_Analysis_on_Point_Cloud/modules/repsurface_utils.py):
   sample_and_group:12  square_distance:129  farthest_point_sample:150  index_points:174
   knn_point:193  SurfaceAbstractionCD:256  Linear:380  LocalMerge:406  LocalTrans:448
-  KeepHighResolutionModule:542  group_by_umbrella:106  UmbrellaSurfaceConstructor:321
+  KeepHighResolutionModule:542  resort_points:86  group_by_umbrella:106  SurfaceAbstraction:206
+  UmbrellaSurfaceConstructor:321 (shared with pointnet2_utils.py, where they are defined)
 (polar_utils / recons_utils: the sibling modules of the same names).
 """
 import torch
@@ -14,7 +15,8 @@ import torch.nn.functional as F
 from .. import ops
 from ..ops import (farthest_point_sample, index_points, knn_point, query_ball_point, query_knn_point,  # noqa: F401
                    sample, square_distance)
-from .pointnet2_utils import Linear, LocalTrans, local_trans_pair, stacked_param_groups
+from .pointnet2_utils import (Linear, LocalTrans, UmbrellaSurfaceConstructor, group_by_umbrella,  # noqa: F401
+                               local_trans_pair, resort_points, stacked_param_groups)
 
 
 def sample_and_group(npoint, radius, nsample, center, normal, feature, return_normal=True, return_polar=False,
@@ -58,6 +60,45 @@ def _conv_bn(x, conv, bn, slope):
     y = ops.linear_bn_act(x.reshape(B, S * G, C), conv.weight.view(conv.out_channels, conv.in_channels), conv.bias,
                           bn, slope)
     return y.view(B, S, G, conv.out_channels)
+
+
+class SurfaceAbstraction(nn.Module):
+    """RepSurf set abstraction without the split first layer (reference :206-254): FPS + ball query (or
+    the whole cloud) + shared MLP (1x1 Conv2d + BatchNorm2d + ReLU per layer) + max over the group."""
+
+    def __init__(self, npoint, radius, nsample, in_channel, mlp, group_all, return_polar=True, return_normal=True,
+                 cuda=False):
+        super().__init__()
+        self.npoint, self.radius, self.nsample = npoint, radius, nsample
+        self.return_normal, self.return_polar = return_normal, return_polar
+        self.cuda_ops = cuda
+        self.group_all = group_all
+        self.mlp_convs = nn.ModuleList()
+        self.mlp_bns = nn.ModuleList()
+        last = in_channel
+        for out_channel in mlp:
+            self.mlp_convs.append(nn.Conv2d(last, out_channel, 1))
+            self.mlp_bns.append(nn.BatchNorm2d(out_channel))
+            last = out_channel
+
+    def forward(self, center, normal, feature):
+        normal = normal.permute(0, 2, 1).contiguous()
+        center = center.permute(0, 2, 1).contiguous()
+        if feature is not None:
+            feature = feature.permute(0, 2, 1).contiguous()
+        if self.group_all:
+            new_center, new_normal, new_feature = sample_and_group_all(center, normal, feature,
+                                                                       return_polar=self.return_polar,
+                                                                       return_normal=self.return_normal)
+        else:
+            new_center, new_normal, new_feature = sample_and_group(self.npoint, self.radius, self.nsample, center,
+                                                                   normal, feature, return_polar=self.return_polar,
+                                                                   return_normal=self.return_normal, cuda=self.cuda_ops)
+        new_feature = new_feature.contiguous()
+        for conv, bn in zip(self.mlp_convs, self.mlp_bns):
+            new_feature = _conv_bn(new_feature, conv, bn, 0.0)
+        new_feature = new_feature.max(dim=2)[0].permute(0, 2, 1)
+        return new_center.permute(0, 2, 1), new_normal.permute(0, 2, 1), new_feature
 
 
 class SurfaceAbstractionCD(nn.Module):
@@ -107,58 +148,6 @@ class SurfaceAbstractionCD(nn.Module):
             new_feature = _conv_bn(new_feature, conv, bn, 0.0)
         new_feature = new_feature.max(dim=2)[0].permute(0, 2, 1)          # max over the group -> [B,C,S]
         return new_center.permute(0, 2, 1), new_normal.permute(0, 2, 1), new_feature
-
-
-def group_by_umbrella(xyz, new_xyz, k=9, cuda=False):
-    """reference :106-126.  [B,N',k-1,3 (centre, p_i, p_i+1),3]: the k-1 nearest neighbours of each
-    point of new_xyz (the nearest dropped), relative to it, sorted by azimuth, paired cyclically."""
-    from .polar_utils import xyz2sphere
-    idx = query_knn_point(k, xyz, new_xyz)
-    rel = index_points(xyz, idx)[:, :, 1:] - new_xyz.unsqueeze(-2)
-    order = xyz2sphere(rel)[..., 2].argsort(dim=-1, stable=True)
-    srt = torch.gather(rel, 2, order.unsqueeze(-1).expand(-1, -1, -1, 3)).unsqueeze(-2)
-    return torch.cat([torch.zeros_like(srt), srt, torch.roll(srt, -1, dims=-3)], dim=-2)
-
-
-class UmbrellaSurfaceConstructor(nn.Module):
-    """Umbrella-based surface abstraction (reference :321-376): per point the k-1 triangles around it
-    -> (centre | polar | normal | position) -> three 1x1 convolutions (BatchNorm + ReLU after the
-    first two) -> sum / mean / max over the triangles.  [B,3,N] -> [B,in_channel,N].
-    The triangle features come from one fused kernel (ops.umbrella_features), the convolutions run
-    as the fp32-MFMA Linear unit over the B*N*(k-1) rows; parameter names equal the reference's."""
-
-    def __init__(self, k, in_channel, aggr_type='sum', return_dist=False, random_inv=True, cuda=False):
-        super().__init__()
-        self.k = k
-        self.return_dist = return_dist
-        self.random_inv = random_inv
-        self.aggr_type = aggr_type
-        self.cuda_ops = cuda      # the reference stores this as `self.cuda`, shadowing nn.Module.cuda
-        self.mlps = nn.Sequential(
-            nn.Conv2d(in_channel, in_channel, 1, bias=False), nn.BatchNorm2d(in_channel), nn.ReLU(True),
-            nn.Conv2d(in_channel, in_channel, 1, bias=True), nn.BatchNorm2d(in_channel), nn.ReLU(True),
-            nn.Conv2d(in_channel, in_channel, 1, bias=True))
-
-    def forward(self, center):
-        center = center.permute(0, 2, 1).contiguous()
-        B, N, _ = center.shape
-        sign = None
-        if self.random_inv:       # per-cloud flip drawn from the CPU generator, as the reference does
-            sign = torch.randint(0, 2, (B, 1, 1)).float().view(B) * 2. - 1.
-        f = ops.umbrella_features(center, self.k, cloud_sign=sign, return_dist=self.return_dist)   # [B,N,G,CH]
-        G, CH = f.shape[2], f.shape[3]
-        m = self.mlps
-        x = f.view(B, N * G, CH)
-        x = ops.linear_bn_act(x, m[0].weight.view(CH, CH), None, m[1], 0.0)
-        x = ops.linear_bn_act(x, m[3].weight.view(CH, CH), m[3].bias, m[4], 0.0)
-        x = ops.linear(x, m[6].weight.view(CH, CH), m[6].bias).view(B, N, G, CH)
-        if self.aggr_type == 'max':
-            x = x.max(dim=2)[0]
-        elif self.aggr_type == 'avg':
-            x = x.mean(dim=2)
-        else:
-            x = x.sum(dim=2)
-        return x.permute(0, 2, 1)
 
 
 class LocalMerge(nn.Module):
