@@ -83,12 +83,14 @@ def forward_only(model, x, feeder, iters=50):
             for _ in range(2):
                 feeder.begin_pass()
                 model(x)
+                feeder.end_pass()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             feeder.begin_pass()
             model(x)
+            feeder.end_pass()
         for _ in range(5):
             feeder.refill()
             g.replay()

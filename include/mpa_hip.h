@@ -49,6 +49,14 @@ const char *mpa_last_hip_error_string(void);
 int mpa_fps_f32(const float *xyz, int B, int N, int S, const int64_t *start_idx,
                 int64_t *out_idx, float *out_xyz, void *stream);
 
+/* farthest_point_sample on rows of any width C (the reference function takes xyz [B,N,C] for any C and sums
+ * the squared differences over all channels, :103-104; dataset/ShapeNetDataLoader.py:127-133 samples on
+ * xyz|normal rows).  points [B,N,C]; same start_idx / out_idx contract and the same tie rule as mpa_fps_f32;
+ * the channel sum follows torch.sum's order on the reference's CPU path, so indices
+ * are bit-exact for every C.  Not on the models' hot path: rows are re-read from L2 each iteration. */
+int mpa_fps_generic_f32(const float *points, int B, int N, int C, int S, const int64_t *start_idx,
+                        int64_t *out_idx, void *stream);
+
 /* ---- square_distance: modules/pointnet2_utils.py:190-209.  src [B,S,C], dst [B,N,C] -> out [B,S,N];
  * bit-exact with the reference CPU result (FMA chain dot, separately rounded norms). */
 int mpa_square_distance_f32(const float *src, const float *dst, int B, int S, int N, int C,
@@ -238,11 +246,14 @@ int mpa_three_interp_bwd_f32(const float *grad_out, const int64_t *idx, const fl
 /* ---- optimizer step over flat buckets (the training loop of tool/train_cls_scanobjectnn.py:205-216
  * uses torch.optim.Adam; gradients here live in a few flat buffers, so one elementwise pass per
  * bucket replaces ~300 per-parameter launches).  torch.optim.Adam arithmetic, no amsgrad.
- * `step` is a device scalar holding the (already advanced) step count t. */
+ * `step` is a device scalar holding the (already advanced) step count t.  `hyper` (optional) is a device
+ * array [lr, weight_decay] that overrides the by-value `lr` / `weight_decay`: values passed by value are
+ * frozen into a captured HIP graph, device scalars can be rewritten between replays (learning-rate
+ * schedules: tool/train_cls_scanobjectnn.py:219-238, tool/train_partseg.py:152-221). */
 int mpa_scalar_add_f32(float *x, float a, void *stream);
 int mpa_adam_step_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long long n,
                       float lr, float beta1, float beta2, float eps, float weight_decay,
-                      const float *step, void *stream);
+                      const float *step, const float *hyper, void *stream);
 
 #ifdef __cplusplus
 }

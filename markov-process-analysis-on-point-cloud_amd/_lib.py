@@ -27,6 +27,7 @@ _vp, _i, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
 # name -> argtypes (restype is int unless noted); order must match include/mpa_hip.h
 SIGNATURES = {
     "mpa_fps_f32": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "mpa_fps_generic_f32": [_vp, _i, _i, _i, _i, _vp, _vp, _vp],
     "mpa_square_distance_f32": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "mpa_knn_f32": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp],
     "mpa_ball_query_f32": [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp],
@@ -49,7 +50,7 @@ SIGNATURES = {
     "mpa_bn_act_bwd_reduce_f32": [_vp] * 6 + [_f, _i, _i, _i, _vp, _i, _vp],
     "mpa_bn_act_bwd_apply_f32": [_vp] * 7 + [_i, _f, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "mpa_scalar_add_f32": [_vp, _f, _vp],
-    "mpa_adam_step_f32": [_vp, _vp, _vp, _vp, ctypes.c_longlong, _f, _f, _f, _f, _f, _vp, _vp],
+    "mpa_adam_step_f32": [_vp, _vp, _vp, _vp, ctypes.c_longlong, _f, _f, _f, _f, _f, _vp, _vp, _vp],
     "mpa_upsample_workspace_bytes": [_i, _i, _i, _i],
     "mpa_upsample_mean_fwd_f32": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, ctypes.c_size_t, _vp],
     "mpa_upsample_mean_bwd_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],

@@ -5,7 +5,10 @@
 //   g' = g + wd*p;  m = lerp(m, g', 1-b1);  v = b2*v + (1-b2)*g'^2;
 //   p -= (lr / (1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
 // The step count t lives on the device (so a captured HIP graph replays with the right bias
-// correction); mpa_scalar_add_f32 advances it.
+// correction); mpa_scalar_add_f32 advances it.  The learning rate and the weight decay can live on the
+// device too (`hyper` = [lr, weight_decay]): by-value kernel arguments are frozen into a captured graph,
+// and the reference's training loops change the rate every epoch (StepLR / CosineAnnealingLR,
+// tool/train_cls_scanobjectnn.py:219-238, tool/train_partseg.py:152-221).
 #include "mpa_common.h"
 
 namespace {
@@ -15,8 +18,9 @@ __global__ void scalar_add_kernel(float *x, float a) { *x += a; }
 __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *__restrict__ g,
                                                    float *__restrict__ m, float *__restrict__ v, long long n,
                                                    float lr, float b1, float b2, float eps, float wd,
-                                                   const float *__restrict__ step)
+                                                   const float *__restrict__ step, const float *__restrict__ hyper)
 {
+    if (hyper != nullptr) { lr = hyper[0]; wd = hyper[1]; }
     const float t = *step;
     const float bc1 = 1.0f - powf(b1, t);
     const float bc2_sqrt = sqrtf(1.0f - powf(b2, t));
@@ -66,7 +70,7 @@ extern "C" int mpa_scalar_add_f32(float *x, float a, void *stream)
 
 extern "C" int mpa_adam_step_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long long n,
                                  float lr, float beta1, float beta2, float eps, float weight_decay,
-                                 const float *step, void *stream)
+                                 const float *step, const float *hyper, void *stream)
 {
     MPA_CLEAR_ERROR();
     if (!param || !grad || !exp_avg || !exp_avg_sq || !step || n <= 0) return MPA_EINVAL;
@@ -75,7 +79,7 @@ extern "C" int mpa_adam_step_f32(float *param, const float *grad, float *exp_avg
     long long g = (n / 4 + 255) / 256;
     g = g > 2048 ? 2048 : (g < 1 ? 1 : g);
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
-                       exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step);
+                       exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, hyper);
     MPA_LAUNCH_CHECK();
     return MPA_OK;
 }

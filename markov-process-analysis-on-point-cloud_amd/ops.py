@@ -105,7 +105,9 @@ def _fps_start(B, N, device, start_idx=None):
     """First index of every cloud: from the global CPU generator exactly as in the reference
     (torch.randint on CPU, then moved), or from the graph-safe feeder when one is installed."""
     if start_idx is None and _FPS_START_HOOK is not None:
-        return _FPS_START_HOOK(B, N, device)          # runtime.FpsStartFeeder
+        fed = _FPS_START_HOOK(B, N, device)           # runtime.FpsStartFeeder (None outside a fed pass)
+        if fed is not None:
+            return fed
     if start_idx is None:
         start_idx = torch.randint(0, N, (B,), dtype=torch.long)
     if not start_idx.is_cuda and (int(start_idx.min()) < 0 or int(start_idx.max()) >= N):
@@ -134,16 +136,19 @@ def fps_and_knn_xyz(fps_in, npoint, k, knn_base, knn_query, start_idx=None):
 
 
 def farthest_point_sample(xyz, npoint, cuda=False, start_idx=None, return_xyz=False):
-    """reference: modules/pointnet2_utils.py:84-109.  xyz [B,N,3] -> int64 [B,npoint].
+    """reference: modules/pointnet2_utils.py:84-109.  xyz [B,N,C] -> int64 [B,npoint] (C == 3: the
+    register-resident kernel of the models' path; any other C: the generic kernel).
     The first index of every cloud comes from the global CPU generator exactly as in the
     reference (torch.randint on CPU, then moved), so equal seeds give equal samples."""
     _dev(xyz)
     xyz = _f32(xyz)
     B, N, C = xyz.shape
-    if C != 3:
-        raise ValueError("farthest_point_sample: the gfx950 kernel samples in xyz space (C == 3), got C=%d" % C)
     start = _fps_start(B, N, xyz.device, start_idx)
     out = torch.empty(B, npoint, dtype=torch.int64, device=xyz.device)
+    if C != 3:
+        # rows of any width (the reference sums the squared differences over all C channels, :103-104)
+        _launch("mpa_fps_generic_f32", _p(xyz), B, N, C, npoint, _p(start), _p(out), _stream())
+        return (out, index_points(xyz, out)) if return_xyz else out
     oxyz = torch.empty(B, npoint, 3, dtype=torch.float32, device=xyz.device) if return_xyz else None
     _launch("mpa_fps_f32", _p(xyz), B, N, npoint, _p(start), _p(out), _p(oxyz), _stream())
     return (out, oxyz) if return_xyz else out
@@ -151,7 +156,8 @@ def farthest_point_sample(xyz, npoint, cuda=False, start_idx=None, return_xyz=Fa
 
 def farthest_point_sample_ragged(clouds, npoint, start_idx=None):
     """FPS of clouds with DIFFERENT point counts in one launch: `clouds` is a list of [N_i, >=3] device
-    tensors -> (idx int64 [B, npoint], padded [B, Nmax, C]).  Every cloud is padded to the longest one
+    tensors -> (idx int64 [B, npoint], padded [B, Nmax, C]); distances run over all C channels, as in the
+    reference.  Every cloud is padded to the longest one
     with copies of its point 0: a copy always carries point 0's running distance and a higher index,
     so it never wins the arg-max -- row i equals farthest_point_sample(clouds[i][None], npoint) of the
     reference, called one cloud at a time in list order (dataset/ShapeNetDataLoader.py:127-133),
@@ -172,7 +178,9 @@ def farthest_point_sample_ragged(clouds, npoint, start_idx=None):
     for i, c in enumerate(clouds):
         if not 0 <= int(start_idx[i]) < int(c.shape[0]):
             raise ValueError("farthest_point_sample_ragged: start_idx[%d] out of range" % i)
-    idx = farthest_point_sample(padded[:, :, :3].contiguous(), npoint, start_idx=start_idx)
+    # the reference hands the WHOLE [1,N,C] row set to farthest_point_sample (xyz | normals when the reader's
+    # normal_channel is on), whose distance sums over all C channels (modules/pointnet2_utils.py:103-104)
+    idx = farthest_point_sample(padded, npoint, start_idx=start_idx)
     return idx, padded
 
 

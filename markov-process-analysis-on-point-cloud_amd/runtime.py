@@ -9,9 +9,9 @@ stream (no allocation, no synchronisation), which is what makes them capturable.
 
 One thing in the reference path is host-side state: farthest_point_sample draws its first index
 per cloud from the global CPU generator (modules/pointnet2_utils.py:96).  FpsStartFeeder keeps
-that behaviour under replay: each FPS call site owns a pinned host buffer + a device buffer, the
-captured graph contains the pinned->device copy, and refill() draws fresh indices from the CPU
-generator (same order, same distribution) before every replay.
+that behaviour under replay: each FPS call site owns a slice of one device buffer that the captured
+kernels read in place, and refill() draws fresh indices from the CPU generator (same calls, same
+order) and ships them with one stream-ordered copy before every replay.
 """
 import torch
 
@@ -25,30 +25,72 @@ _SKIP_OPT = bool(os.environ.get("MPA_DEBUG_SKIP_OPT"))      # profiling aid: rep
 
 
 class FpsStartFeeder:
+    """Graph-safe source of farthest_point_sample's first indices (ops.set_fps_start_hook).
+
+    Every FPS call site of a pass owns a slice of ONE int64 device buffer; a captured graph's FPS kernels
+    read their slices in place (no copy node in the graph).  refill() draws all slices from the global CPU
+    generator -- same calls, same order as the reference's per-call torch.randint -- into a FRESH pinned
+    tensor and issues one stream-ordered H2D copy; torch's pinned-memory allocator does not hand that
+    block out again before the copy has run, so a host that runs many replays ahead never overwrites
+    draws an earlier replay has yet to read (each replay sees exactly its own draws).
+
+    The hook only answers between begin_pass() and end_pass(): any other forward (an evaluation between
+    training steps, vote_classification, ...) falls through to the plain reference path and cannot grow
+    the slot list."""
+
+    CAPACITY = 1 << 16           # start indices per pass (all FPS call sites x clouds)
+
     def __init__(self):
-        self.slots = []
+        self.prefilled = False
+        self.slots = []          # (B, N, offset) per FPS call site, in call order
+        self.total = 0
+        self.dev = None          # int64 [total] device buffer the kernels read
         self.cursor = 0
+        self.active = False
+        self.sealed = False      # True once a graph has been captured over the slots: the layout is fixed
         self.frozen = False      # True: keep the current start indices (debugging / parity runs)
 
     def __call__(self, B, N, device):
+        if not self.active:
+            return None          # not inside a fed pass: ops falls back to the reference's CPU draw
+        capturing = torch.cuda.is_current_stream_capturing()
         if self.cursor == len(self.slots):
-            self.slots.append({"B": B, "N": N, "host": torch.empty(B, dtype=torch.int64).pin_memory(),
-                               "dev": torch.empty(B, dtype=torch.int64, device=device)})
-        slot = self.slots[self.cursor]
-        if slot["B"] != B or slot["N"] != N:
+            if self.sealed or capturing:
+                raise RuntimeError("FPS call sequence grew after the step was captured")
+            if self.dev is None:
+                self.dev = torch.zeros(self.CAPACITY, dtype=torch.int64, device=device)
+            if self.total + B > self.CAPACITY:
+                raise RuntimeError("FpsStartFeeder: more than %d start indices per pass" % self.CAPACITY)
+            self.slots.append((B, N, self.total))
+            self.total += B
+        sB, sN, off = self.slots[self.cursor]
+        if sB != B or sN != N:
             raise RuntimeError("FPS call sequence changed shape under a captured step")
         self.cursor += 1
-        if not self.frozen and not torch.cuda.is_current_stream_capturing():
-            slot["host"].copy_(torch.randint(0, N, (B,), dtype=torch.long))
-        slot["dev"].copy_(slot["host"], non_blocking=True)
-        return slot["dev"]
+        view = self.dev[off:off + B]
+        if not self.frozen and not capturing and not self.prefilled:
+            src = torch.randint(0, N, (B,), dtype=torch.long).pin_memory()
+            view.copy_(src, non_blocking=True)
+        return view
 
-    def begin_pass(self):
+    def begin_pass(self, prefilled=False):
+        """prefilled: the caller has just refill()ed every slot (a replayed or re-run pass)."""
         self.cursor = 0
+        self.active = True
+        self.prefilled = prefilled
+
+    def end_pass(self):
+        self.active = False
+
+    def seal(self):
+        self.sealed = True
 
     def refill(self):
-        for slot in self.slots:
-            slot["host"].copy_(torch.randint(0, slot["N"], (slot["B"],), dtype=torch.long))
+        """Fresh draws for every slot: one pinned tensor, one stream-ordered copy."""
+        if self.frozen or not self.slots:
+            return
+        src = torch.cat([torch.randint(0, N, (B,), dtype=torch.long) for B, N, _ in self.slots]).pin_memory()
+        self.dev[:self.total].copy_(src, non_blocking=True)
 
 
 class GraphedTrainStep:
@@ -91,9 +133,11 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
 
+        self.feeder.refill()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.loss = self._fwd_bwd()
+        self.feeder.seal()
         self.opt_graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.opt_graph):
             self.opt.step()
@@ -101,10 +145,13 @@ class GraphedTrainStep:
     def _fwd_bwd(self):
         self.feeder.begin_pass()
         self.reducer.zero_grad()
-        if self.compute_loss is not None:
-            loss = self.compute_loss(self.model, self.loss_fn, *self.static)
-        else:
-            loss = self.loss_fn(self.model(self.static[0]), *self.static[1:])
+        try:
+            if self.compute_loss is not None:
+                loss = self.compute_loss(self.model, self.loss_fn, *self.static)
+            else:
+                loss = self.loss_fn(self.model(self.static[0]), *self.static[1:])
+        finally:
+            self.feeder.end_pass()
         ops.defer_weight_grads(True)          # dW products are queued during backward ...
         try:
             loss.backward()
@@ -122,6 +169,9 @@ class GraphedTrainStep:
         if is_dist() and world_size() > 1:
             self.reducer.all_reduce()
         if not _SKIP_OPT:
+            sync = getattr(self.opt, "sync_hyper", None)
+            if sync is not None:
+                sync()                       # a scheduler may have moved the learning rate since the last step
             self.opt_graph.replay()
         return self.loss
 

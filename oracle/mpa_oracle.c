@@ -28,8 +28,8 @@
  * C < 8: plain left-to-right sum.  C a multiple of 8: the C squares form C/8 vectors of
  * 8 lanes; min(4, C/8) lane-wise accumulators, accumulator a taking vectors a, a+A, ...;
  * accumulators are combined ((a0+a1)+a2)+a3 lane-wise, then lanes 0..7 left to right.
- * Other C (not on the hot path): vector part as above over floor(C/8)*8, then the tail
- * is added left to right -- documented as unvalidated. */
+ * Other C: vector part as above over floor(C/8)*8, then the tail is added left to right
+ * (validated against the reference's farthest_point_sample at C = 10: tests/golden/round2.npz). */
 static float sum_sq(const float *x, int C)
 {
     if (C < 8) {
@@ -155,6 +155,7 @@ void orc_knn(const float *base, const float *query, int B, int N, int S, int C, 
 void orc_fps(const float *xyz, int B, int N, int C, int S, const int64_t *start, int64_t *out_idx)
 {
     float *dist = (float *)malloc(sizeof(float) * (size_t)N);
+    float *diff = (float *)malloc(sizeof(float) * (size_t)C);
     for (int b = 0; b < B; ++b) {
         const float *P = xyz + (size_t)b * N * C;
         for (int n = 0; n < N; ++n)
@@ -167,13 +168,11 @@ void orc_fps(const float *xyz, int B, int N, int C, int S, const int64_t *start,
             int64_t besti = 0;
             for (int n = 0; n < N; ++n) {
                 const float *p = P + (size_t)n * C;
-                float d0 = p[0] - c[0];
-                float dd = d0 * d0;
-                for (int k = 1; k < C; ++k) {      /* C==3: (dx0^2 + dx1^2) + dx2^2 */
-                    float dk = p[k] - c[k];
-                    float sq = dk * dk;
-                    dd = dd + sq;
-                }
+                /* torch.sum((xyz - centroid)**2, -1): differences rounded, then the A2 sum of
+                 * squares (C == 3: (dx0^2 + dx1^2) + dx2^2; C >= 8: the 8-lane x 4-accumulator order) */
+                for (int k = 0; k < C; ++k)
+                    diff[k] = p[k] - c[k];
+                float dd = sum_sq(diff, C);
                 if (dd < dist[n])
                     dist[n] = dd;
                 if (dist[n] > best) { best = dist[n]; besti = n; }   /* first maximum */
@@ -182,6 +181,7 @@ void orc_fps(const float *xyz, int B, int N, int C, int S, const int64_t *start,
         }
     }
     free(dist);
+    free(diff);
 }
 
 /* A6: query_ball_point(radius, nsample, xyz=base, new_xyz=query): first nsample base

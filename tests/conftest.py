@@ -47,3 +47,8 @@ def golden_seg():
 
 def bits(a):
     return np.ascontiguousarray(a, dtype=np.float32).view(np.int32)
+
+
+@pytest.fixture(scope="session")
+def golden_round2():
+    return load_golden("round2.npz")

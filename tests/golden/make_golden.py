@@ -421,8 +421,85 @@ def gen_seg():
     save("seg_model.npz", d)
 
 
+# ------------------------------------------------------------------ round 2: generic-C FPS, losses, augmentation, Fuse gradients
+def gen_round2():
+    import importlib
+    d = {}
+    # farthest_point_sample on C != 3 (modules/pointnet2_utils.py:84-109 takes any C: the dataset reader
+    # samples on [1,N,6] xyz|normal rows, the stale part-seg variant in feature space)
+    for tag, (B, N, C, S) in {"fpsc_6": (2, 300, 6, 120), "fpsc_10": (2, 200, 10, 64), "fpsc_64": (2, 256, 64, 64),
+                              "fpsc_2": (1, 100, 2, 30)}.items():
+        x = randn((B, N, C), seed=60 + C, scale=0.5)
+        torch.manual_seed(N + C)
+        start = torch.randint(0, N, (B,), dtype=torch.long)
+        torch.manual_seed(N + C)
+        idx = p2.farthest_point_sample(x, S)
+        assert (idx[:, 0] == start).all()
+        d[tag + "/x"], d[tag + "/start"], d[tag + "/idx"] = npy(x), npy(start), npy(idx).astype(np.int16)
+
+    # label-smoothed losses (util/utils.py:74-88 on log-probabilities; pointnet2_part_seg_msg.py:159-180 on logits)
+    utils = importlib.import_module("util.utils")
+    pred = torch.log_softmax(randn((16, 40), seed=71), -1).requires_grad_(True)
+    tgt = torch.randint(0, 40, (16,), generator=torch.Generator().manual_seed(72))
+    loss = utils.SmoothClsLoss()(pred, tgt)
+    d["cls_loss/pred"], d["cls_loss/target"], d["cls_loss/loss"] = npy(pred), npy(tgt), npy(loss)
+    d["cls_loss/gpred"] = npy(torch.autograd.grad(loss, pred)[0])
+    logits = randn((2 * 2048, 50), seed=73, scale=2.0).requires_grad_(True)
+    tgt = torch.randint(0, 50, (2, 2048), generator=torch.Generator().manual_seed(74))
+    loss = seg_mod.get_loss()(logits, tgt, None)
+    d["seg_loss/pred"], d["seg_loss/target"], d["seg_loss/loss"] = npy(logits), npy(tgt).astype(np.int16), npy(loss)
+    d["seg_loss/gpred"] = npy(torch.autograd.grad(loss, logits)[0])
+
+    # train-time augmentation (modules/ptaug_utils.py:22-62): scale then shift, per cloud, drawn with torch.rand on the
+    # batch's device -- here the CPU generator; the draws are stored so the device side can be fed the same numbers
+    ptaug = importlib.import_module("modules.ptaug_utils")
+    batch = randn((4, 6, 128), seed=75)
+    a = Namespace(aug_scale=True, aug_shift=True, dataset="ScanObjectNN")
+    aug_args = ptaug.get_aug_args(a)
+    torch.manual_seed(76)
+    draws = [torch.rand(4, 3, 1), torch.rand(4, 3, 1)]          # what the two torch.rand calls will return
+    torch.manual_seed(76)
+    out = ptaug.transform_point_cloud(batch.clone(), a, aug_args)
+    d["aug/batch"], d["aug/out"] = npy(batch), npy(out)
+    d["aug/draw_scale"], d["aug/draw_shift"] = npy(draws[0]), npy(draws[1])
+    d["aug/scale_factor"], d["aug/shift_factor"] = np.float64(aug_args["scale_factor"]), np.float64(aug_args["shift_factor"])
+    torch.manual_seed(76)
+    a2 = Namespace(aug_scale=False, aug_shift=True, dataset="ScanObjectNN")
+    d["aug/out_shift_only"] = npy(ptaug.transform_point_cloud(batch.clone(), a2, aug_args))
+
+    # Fuse backward (modules/pointnet2_utils.py:576-709) at two target levels: the same inputs as fuse.npz
+    B, N = 1, 2048
+    x0 = unit_cloud(B, N, seed=900)
+    torch.manual_seed(17)
+    xs, fps, knn = [x0], [], []
+    for S in (1024, 512, 256, 128):
+        p = p2.farthest_point_sample(xs[-1], S)
+        fps.append(p)
+        xs.append(p2.index_points(xs[-1], p))
+    knn.append(p2.knn_point(8, x0, x0)[1])
+    for lvl in range(1, 5):
+        knn.append(p2.knn_point(8, xs[lvl - 1], xs[lvl])[1])
+    chans = (64, 64, 64, 128, 256)
+    for lvl, npnt in ((3, 256), (1, 1024)):
+        feats = [randn((B, xs[l].shape[1], chans[l]), seed=910 + l).requires_grad_(True) for l in range(5)]
+        m = fill_state(p2.Fuse(*chans), seed=6).train()
+        out = m(npnt, f0=feats[0], f1=feats[1], f2=feats[2], f3=feats[3], f4=feats[4],
+                FPS_0=fps[0], FPS_1=fps[1], FPS_2=fps[2], FPS_3=fps[3],
+                knn_0=knn[0], knn_1=knn[1], knn_2=knn[2], knn_3=knn[3], knn_4=knn[4],
+                xyz0=xs[0], xyz1=xs[1], xyz2=xs[2], xyz3=xs[3], xyz4=xs[4])[lvl]
+        (out * randn(out.shape, seed=4242)).sum().backward()
+        for l in range(5):
+            d["fuse_bwd%d/gf%d" % (lvl, l)] = npy(feats[l].grad)
+        for n, p_ in m.named_parameters():
+            if p_.grad is not None:
+                d["fuse_bwd%d/g.%s" % (lvl, n)] = npy(p_.grad)
+    save("round2.npz", d)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["index", "blocks", "fuse", "sa", "umbrella", "repsurf2x", "cls", "seg"]
+    which = sys.argv[1:] or ["index", "blocks", "fuse", "sa", "umbrella", "repsurf2x", "cls", "seg", "round2"]
+    if "round2" in which:
+        gen_round2()
     if "umbrella" in which:
         gen_umbrella()
     if "repsurf2x" in which:

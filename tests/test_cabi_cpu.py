@@ -43,7 +43,7 @@ def test_argument_validation_without_gpu():
     assert lib.mpa_fps_f32(None, 1, 16, 4, None, None, None, None) == -1
     assert lib.mpa_knn_f32(None, None, 1, 16, 4, 3, 8, None, None, None) == -1
     assert lib.mpa_gather_fwd_f32(None, None, 0, 0, 0, 0, None, None) == -1
-    assert lib.mpa_adam_step_f32(None, None, None, None, 0, 0.0, 0.0, 0.0, 0.0, 0.0, None, None) == -1
+    assert lib.mpa_adam_step_f32(None, None, None, None, 0, 0.0, 0.0, 0.0, 0.0, 0.0, None, None, None) == -1
 
 
 def test_no_cpu_fallback():

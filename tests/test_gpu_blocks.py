@@ -167,6 +167,85 @@ def test_fuse(P, golden_fuse):
         close(out[lvl], g["out%d" % lvl], what="fuse level %d" % lvl)
 
 
+@pytest.mark.parametrize("lvl", [3, 1])
+def test_fuse_backward(P, golden_fuse, golden_round2, lvl):
+    """Fuse gradients with respect to all five states and every Linear it owns, per block, against the
+    reference (tests/golden/round2.npz): TOL x the block's gradient scale."""
+    g, g2 = golden_fuse, golden_round2
+    x0 = G(g["x0"])
+    fps = [GL(g["fps%d" % l]) for l in range(4)]
+    knn = [GL(g["knn%d" % l]) for l in range(5)]
+    feats = [G(g["f%d" % l]).requires_grad_(True) for l in range(5)]
+    xs = [x0]
+    for p in fps:
+        xs.append(P.index_points(xs[-1], p))
+    m = fill_state(P.Fuse(64, 64, 64, 128, 256), seed=6).cuda().train()
+    out = m(xs[lvl].shape[1], f0=feats[0], f1=feats[1], f2=feats[2], f3=feats[3], f4=feats[4],
+            FPS_0=fps[0], FPS_1=fps[1], FPS_2=fps[2], FPS_3=fps[3],
+            knn_0=knn[0], knn_1=knn[1], knn_2=knn[2], knn_3=knn[3], knn_4=knn[4],
+            xyz0=xs[0], xyz1=xs[1], xyz2=xs[2], xyz3=xs[3], xyz4=xs[4])[lvl]
+    (out * randn(out.shape, seed=4242).cuda()).sum().backward()
+    pre = "fuse_bwd%d" % lvl
+    for l in range(5):
+        close(feats[l].grad, g2["%s/gf%d" % (pre, l)], what="d f%d" % l)
+    scale = max(float(np.abs(v).max()) for k, v in g2.items() if k.startswith(pre + "/g."))
+    for n, p_ in m.named_parameters():
+        key = "%s/g.%s" % (pre, n)
+        assert (p_.grad is not None) == (key in g2), n
+        if p_.grad is not None:
+            close(p_.grad, g2[key], what=n, scale=scale)
+
+
+def test_losses_golden(golden_round2):
+    """The two label-smoothed losses of the timed training steps against the reference's own
+    (util/utils.py:74-88, models/repsurf/pointnet2_part_seg_msg.py:159-180): value and gradient."""
+    import mpa_amd  # noqa: F401
+    from mpa_amd.models.repsurf.repsurf_ssg_umb import SmoothClsLoss
+    from mpa_amd.models.repsurf.pointnet2_part_seg_msg import get_loss
+    g = golden_round2
+    pred = G(g["cls_loss/pred"]).requires_grad_(True)
+    loss = SmoothClsLoss()(pred, GL(g["cls_loss/target"]))
+    assert abs(float(loss) - float(g["cls_loss/loss"])) < 1e-6
+    close(torch.autograd.grad(loss, pred)[0], g["cls_loss/gpred"], tol=1e-7, what="cls loss grad")
+    pred = G(g["seg_loss/pred"]).requires_grad_(True)
+    loss = get_loss()(pred, GL(g["seg_loss/target"]), None)
+    assert abs(float(loss) - float(g["seg_loss/loss"])) < 2e-6
+    close(torch.autograd.grad(loss, pred)[0], g["seg_loss/gpred"], tol=1e-8, what="seg loss grad")
+
+
+def test_ptaug_golden(golden_round2, monkeypatch):
+    """modules/ptaug_utils.py:22-62 on the device.  The reference draws with torch.rand on the batch's
+    device, so the random stream is device-specific by construction; the arithmetic and the ORDER of the
+    draws (scale, then shift) are pinned by feeding the device side the reference run's own draws."""
+    import mpa_amd  # noqa: F401
+    from mpa_amd.modules import ptaug_utils as A
+    g = golden_round2
+    a = Namespace(aug_scale=True, aug_shift=True, dataset="ScanObjectNN")
+    aug = A.get_aug_args(a)
+    assert aug == {"scale_factor": float(g["aug/scale_factor"]), "shift_factor": float(g["aug/shift_factor"])}
+    draws = [G(g["aug/draw_scale"]), G(g["aug/draw_shift"])]
+    real_rand = torch.rand
+
+    def fed(*shape, **kw):
+        assert tuple(shape) == (4, 3, 1) and kw.get("device").type == "cuda"
+        return draws.pop(0)
+
+    monkeypatch.setattr(torch, "rand", fed)
+    out = A.transform_point_cloud(G(g["aug/batch"]).clone(), a, aug)
+    monkeypatch.setattr(torch, "rand", real_rand)
+    assert not draws
+    assert np.array_equal(out.cpu().numpy(), g["aug/out"])              # same fp32 operations: same bits
+    draws = [G(g["aug/draw_scale"])]          # shift only: the FIRST draw of the same seed is the shift
+    monkeypatch.setattr(torch, "rand", lambda *s, **k: draws.pop(0))
+    out = A.transform_point_cloud(G(g["aug/batch"]).clone(), Namespace(aug_scale=False, aug_shift=True), aug)
+    monkeypatch.setattr(torch, "rand", real_rand)
+    assert np.array_equal(out.cpu().numpy(), g["aug/out_shift_only"])
+    # and with the real device generator: per-cloud factors inside the stated ranges, label passed through
+    b = G(g["aug/batch"]).clone()
+    o, lab = A.transform_point_cloud(b.clone(), a, aug, label="L")
+    assert lab == "L" and torch.equal(o[:, 3:], b[:, 3:])
+
+
 # ------------------------------------------------------------------------------- whole models
 class _ForcedKnn:
     """Teacher forcing of the neighbourhood choice for whole-model parity.  GPU features differ
@@ -411,6 +490,150 @@ def test_sample_legacy_helper(P):
 
 
 # --------------------------------------------------------------------- HIP-graph train step
+def _small_cls_step(lr=1e-3, B=4):
+    import mpa_amd  # noqa: F401
+    from mpa_amd.models.repsurf.repsurf_ssg_umb import Model, SmoothClsLoss
+    from mpa_amd.runtime import GraphedTrainStep
+    from param_fill import unit_cloud
+    dev = torch.device("cuda")
+    x = unit_cloud(B, 1024, seed=3).transpose(1, 2).contiguous().to(dev)
+    y = torch.arange(B, device=dev) % 40
+    torch.manual_seed(0)
+    model = Model(Namespace(num_point=1024, return_dist=True, cuda_ops=True, num_class=40)).to(dev).train()
+    model.drop1.p = model.drop2.p = 0.0
+    return model, GraphedTrainStep(model, SmoothClsLoss(), (x, y), lr=lr), x, y
+
+
+def test_graphed_step_follows_the_learning_rate_schedule():
+    """The learning rate is a device scalar of the captured optimizer graph: a torch scheduler attached to
+    FlatAdam changes the step size of later replays (the reference steps StepLR / CosineAnnealingLR every
+    epoch, tool/train_cls_scanobjectnn.py:219-238).  Adam's update is lr * m_hat / (sqrt(v_hat) + eps), so
+    with the gradients held fixed the parameter delta of a replay scales exactly with the rate."""
+    model, step, x, y = _small_cls_step(lr=1e-3)
+    try:
+        sched = torch.optim.lr_scheduler.StepLR(step.opt, step_size=1, gamma=0.25)
+        flat = step.opt.groups[0]["p"]
+        m0, v0, t0 = step.opt.groups[0]["m"].clone(), step.opt.groups[0]["v"].clone(), step.opt.step_count.clone()
+        step.feeder.frozen = True                      # same samples in both replays: same gradients
+
+        def delta():
+            before = flat.clone()
+            step.opt.groups[0]["m"].copy_(m0)
+            step.opt.groups[0]["v"].copy_(v0)
+            step.opt.step_count.copy_(t0)
+            flat_before = before.clone()
+            step(x, y)
+            torch.cuda.synchronize()
+            d = (flat - flat_before).clone()
+            flat.copy_(before)                          # undo: both replays start from the same parameters
+            return d
+
+        d1 = delta()
+        sched.step()                                    # lr 1e-3 -> 2.5e-4
+        assert abs(step.opt.param_groups[0]["lr"] - 2.5e-4) < 1e-12
+        d2 = delta()
+        assert float(d1.abs().max()) > 0
+        ratio = d2.double().norm() / d1.double().norm()
+        assert abs(float(ratio) - 0.25) < 1e-3, float(ratio)
+        # and against torch.optim.Adam's arithmetic at the new rate, on the same (m, v, t, grad)
+        g = step.opt.groups[0]["g"]
+        b1, b2, eps = 0.9, 0.999, 1e-8
+        t = float(t0) + 1
+        m = m0 + (1 - b1) * (g - m0)
+        v = b2 * v0 + (1 - b2) * g * g
+        want = -(2.5e-4 / (1 - b1 ** t)) * m / (v.sqrt() / (1 - b2 ** t) ** 0.5 + eps)
+        # (d2 is a difference of fp32 parameters: it carries half an ulp of the parameter itself)
+        assert float((d2 - want).abs().max()) <= 2e-7 * max(1.0, float(flat.abs().max())) + 1e-3 * float(want.abs().max())
+    finally:
+        step.close()
+
+
+def test_fps_feeder_scope_and_draw_fidelity():
+    """runtime.FpsStartFeeder: (a) a forward outside the captured step (evaluation between training steps)
+    neither grows the slot list nor is fed -- it takes the reference's plain CPU draw; (b) replays see
+    exactly the draws of their own refill, in the reference's call order, however far the host runs ahead."""
+    from mpa_amd import ops
+    model, step, x, y = _small_cls_step()
+    try:
+        nslots = len(step.feeder.slots)
+        assert nslots == 5 and step.feeder.total == 5 * x.shape[0]
+        step(x, y)
+        model.eval()
+        with torch.no_grad():
+            model(x)                                    # e.g. the per-epoch evaluation
+        model.train()
+        step(x, y)
+        torch.cuda.synchronize()
+        assert len(step.feeder.slots) == nslots and step.feeder.total == 5 * x.shape[0]
+        # (b): queue several replays without synchronising; afterwards the buffer holds the LAST refill's
+        # draws, which are the next torch.randint calls of the seeded CPU generator in slot order
+        torch.manual_seed(1234)
+        for _ in range(8):
+            step(x, y)
+        torch.manual_seed(99)
+        step(x, y)
+        torch.cuda.synchronize()
+        torch.manual_seed(99)
+        want = torch.cat([torch.randint(0, N, (B,), dtype=torch.long) for B, N, _ in step.feeder.slots])
+        assert torch.equal(step.feeder.dev[:step.feeder.total].cpu(), want)
+    finally:
+        step.close()
+    assert ops._FPS_START_HOOK is None
+
+
+def test_max_over_points_under_graph_replay(P):
+    """DESIGN section 5, settled on a minimal torch-only graph (tools/graph_max_probe.py, output kept in
+    profiles/r02_graph_max_probe.txt): on this stack torch's single-stage x.max(dim=1) over 2048 points
+    per output -- its multi-workgroup reduction -- returns wrong values from the second replay of a
+    captured HIP graph on (eager is right, the input buffer is right), with or without a backward in the
+    graph; the two-stage form of modules/pointnet2_utils._max_over_points (<= 64 points per stage, one
+    workgroup per output) is right on every replay.  This test holds the staged form to that, values and
+    arg-max routing; the single-stage outcome is reported, not asserted (it is torch's to fix)."""
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(32, 2048, 64, generator=g).to(dev).requires_grad_(True)
+    w = torch.randn(32, 64, generator=g).to(dev)
+
+    def capture(fmax):
+        def run():
+            x.grad = None
+            v = fmax(x)
+            loss = (v * w).mean()
+            loss.backward()
+            return v
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                run()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            v = run()
+        return graph, v, x.grad
+
+    staged = capture(lambda t: P._max_over_points(t)[:, 0])
+    single = capture(lambda t: t.max(dim=1)[0])
+    single_ok = []
+    for it in range(4):
+        new = torch.randn(32, 2048, 64, generator=g)
+        with torch.no_grad():
+            x.copy_(new)
+        want_v, want_i = new.max(dim=1)
+        want_g = torch.zeros_like(new).scatter_(1, want_i.unsqueeze(1), (w.cpu() / w.numel()).unsqueeze(1))
+        graph, v, grad = staged
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(v.cpu(), want_v), "staged max, replay %d" % it
+        assert torch.allclose(grad.cpu(), want_g, rtol=1e-6, atol=1e-9), "staged max routing, replay %d" % it
+        graph, v, grad = single
+        graph.replay()
+        torch.cuda.synchronize()
+        single_ok.append(bool(torch.equal(v.cpu(), want_v)))
+    print("single-stage torch max under replay, per replay:", single_ok)
+
+
 def test_graphed_partseg_step_replays_stay_finite():
     """The captured part-seg step (direct gradients, grouped dW, FlatAdam) replayed several times:
     regression for torch's multi-workgroup max reduction going wrong from the second replay on

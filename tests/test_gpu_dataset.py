@@ -98,7 +98,9 @@ def test_shapenet_items_and_batches(co, tmp_path):
         xyzn = data[:, :6].copy()
         xyzn[:, :3] = R.dataset_pc_normalize(xyzn[:, :3])
         start = torch.randint(0, len(data), (1,), dtype=torch.long)
-        idx = co.farthest_point_sample(xyzn[None, :, :3].copy(), 128, start.numpy())[0]
+        # the reference samples on the whole xyz|normal row (dataset/ShapeNetDataLoader.py:127-133 hands the
+        # [1,N,6] tensor to farthest_point_sample, which sums over all channels)
+        idx = co.farthest_point_sample(xyzn[None].copy(), 128, start.numpy())[0]
         assert pts.dtype == np.float32 and np.array_equal(pts, xyzn[idx]), i
         assert seg.dtype == np.float32 and np.array_equal(seg, data[idx, -1]), i
         assert cls.dtype == np.int32 and cls.shape == (1,) and int(cls[0]) == ds.classes[cat]

@@ -365,7 +365,29 @@ def test_fused_fps_knn_xyz_equals_separate_launches(ops, B, fN, fS, N, S):
     fidx0, fxyz0 = ops.farthest_point_sample(fin, fS, start_idx=start, return_xyz=True)
     dist0, idx0 = ops.knn_point(8, base, query)
     assert torch.equal(fidx, fidx0) and torch.equal(fxyz, fxyz0)
-    assert torch.equal(idx, idx0) and torch.equal(bits(dist.cpu().numpy()) if False else dist, dist0)
+    assert torch.equal(idx, idx0) and torch.equal(dist, dist0)          # same bits: fp32 compared exactly
+
+
+# --------------------------------------------------------------------------- FPS on rows of any width
+@pytest.mark.parametrize("tag", ["fpsc_2", "fpsc_6", "fpsc_10", "fpsc_64"])
+def test_fps_any_channel_count_golden(ops, golden_round2, tag):
+    """reference farthest_point_sample on [B,N,C], C != 3 (modules/pointnet2_utils.py:84-109): bit-exact indices."""
+    g = golden_round2
+    S = g[tag + "/idx"].shape[1]
+    idx, sub = ops.farthest_point_sample(G(g[tag + "/x"]), S, start_idx=torch.from_numpy(g[tag + "/start"]),
+                                         return_xyz=True)
+    assert np.array_equal(idx.cpu().numpy(), g[tag + "/idx"].astype(np.int64))
+    want = np.take_along_axis(g[tag + "/x"], g[tag + "/idx"].astype(np.int64)[..., None], 1)
+    assert np.array_equal(sub.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("B,N,C,S", [(3, 1000, 6, 400), (2, 513, 16, 513), (2, 64, 128, 20), (1, 12000, 5, 64), (2, 33, 9, 40)])
+def test_fps_any_channel_count_oracle(ops, co, B, N, C, S):
+    x = randn((B, N, C), seed=N + C)
+    x[0, 5] = x[0, 2]                                    # a duplicated row: ties -> lowest index
+    start = torch.randint(0, N, (B,), generator=torch.Generator().manual_seed(C))
+    idx = ops.farthest_point_sample(x.cuda(), S, start_idx=start)
+    assert np.array_equal(idx.cpu().numpy(), co.farthest_point_sample(x.numpy(), S, start.numpy()))
 
 
 # --------------------------------------------------------------------------- grouped weight gradients

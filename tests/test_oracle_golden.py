@@ -265,3 +265,53 @@ def test_ref_cpu_repsurf_2x_model():
     m.train()
     torch.manual_seed(5)
     assert np.abs(m(pts.clone()).detach().numpy() - g["out_train"]).max() < 1e-5
+
+
+# ------------------------------------------------------------------ round 2 fixtures (tests/golden/round2.npz)
+@pytest.mark.parametrize("tag", ["fpsc_2", "fpsc_6", "fpsc_10", "fpsc_64"])
+def test_c_fps_any_channel_count(golden_round2, tag):
+    """farthest_point_sample on rows of width C != 3 (reference modules/pointnet2_utils.py:84-109): the
+    channel sum follows torch.sum's order (Appendix A2, incl. the C % 8 tail at C = 10)."""
+    g = golden_round2
+    S = g[tag + "/idx"].shape[1]
+    idx = co.farthest_point_sample(g[tag + "/x"], S, g[tag + "/start"])
+    assert np.array_equal(idx, g[tag + "/idx"].astype(np.int64))
+
+
+def test_ref_cpu_losses(golden_round2):
+    """SmoothClsLoss (util/utils.py:74-88) and get_loss (pointnet2_part_seg_msg.py:159-180)."""
+    g = golden_round2
+    pred = T(g["cls_loss/pred"]).requires_grad_(True)
+    loss = R.smooth_cls_loss(pred, L(g["cls_loss/target"]))
+    assert abs(float(loss) - float(g["cls_loss/loss"])) < 1e-6
+    assert np.abs(torch.autograd.grad(loss, pred)[0].numpy() - g["cls_loss/gpred"]).max() < 1e-7
+    pred = T(g["seg_loss/pred"]).requires_grad_(True)
+    loss = R.partseg_loss(pred, L(g["seg_loss/target"]))
+    assert abs(float(loss) - float(g["seg_loss/loss"])) < 1e-6
+    assert np.abs(torch.autograd.grad(loss, pred)[0].numpy() - g["seg_loss/gpred"]).max() < 1e-8
+
+
+@pytest.mark.parametrize("lvl", [3, 1])
+def test_ref_cpu_fuse_backward(golden_fuse, golden_round2, lvl):
+    g, g2 = golden_fuse, golden_round2
+    x0 = T(g["x0"])
+    fps = [L(g["fps%d" % l]) for l in range(4)]
+    knn = [L(g["knn%d" % l]) for l in range(5)]
+    feats = [T(g["f%d" % l]).requires_grad_(True) for l in range(5)]
+    xs = [x0]
+    for p in fps:
+        xs.append(R.index_points(xs[-1], p))
+    m = fill_state(R.Fuse(64, 64, 64, 128, 256), seed=6).train()
+    out = m(xs[lvl].shape[1], f0=feats[0], f1=feats[1], f2=feats[2], f3=feats[3], f4=feats[4],
+            FPS_0=fps[0], FPS_1=fps[1], FPS_2=fps[2], FPS_3=fps[3],
+            knn_0=knn[0], knn_1=knn[1], knn_2=knn[2], knn_3=knn[3], knn_4=knn[4],
+            xyz0=xs[0], xyz1=xs[1], xyz2=xs[2], xyz3=xs[3], xyz4=xs[4])[lvl]
+    (out * randn(out.shape, seed=4242)).sum().backward()
+    for l in range(5):
+        ref = g2["fuse_bwd%d/gf%d" % (lvl, l)]
+        assert np.abs(feats[l].grad.numpy() - ref).max() < TOL * max(1.0, np.abs(ref).max()), l
+    for n, p_ in m.named_parameters():
+        key = "fuse_bwd%d/g.%s" % (lvl, n)
+        assert (p_.grad is not None) == (key in g2), n
+        if p_.grad is not None:
+            assert np.abs(p_.grad.numpy() - g2[key]).max() < TOL * max(1.0, np.abs(g2[key]).max()), n
