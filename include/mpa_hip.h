@@ -33,6 +33,9 @@ extern "C" {
 #define MPA_EUNSUPPORTED (-2) /* shape outside what the kernels are built for */
 #define MPA_EHIP (-3)     /* HIP launch error */
 
+/* bfloat16 storage (the upper 16 bits of an IEEE fp32, round-to-nearest-even on conversion) */
+typedef uint16_t mpa_bf16;
+
 int mpa_version(void);
 const char *mpa_error_string(int code);
 /* the hipError_t (and its text) behind the calling thread's most recent MPA_EHIP */
@@ -254,6 +257,91 @@ int mpa_scalar_add_f32(float *x, float a, void *stream);
 int mpa_adam_step_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long long n,
                       float lr, float beta1, float beta2, float eps, float weight_decay,
                       const float *step, const float *hyper, void *stream);
+
+/* ==================================================================================================
+ * bf16 feature path (BASELINE configs 3 and 5): the same entry points for FEATURES stored
+ * as bf16 -- activations and their gradients are bf16 in HBM (the path is HBM-bound: half the bytes),
+ * every kernel computes in fp32 registers, and coordinates, distances, indices, BatchNorm statistics,
+ * parameters, parameter gradients and optimizer state stay fp32.  The reference has no reduced-precision
+ * mode (no autocast / GradScaler anywhere), so these follow the SAME formulas as the fp32
+ * entry points above (same reference file:line), rounding only where a feature tensor is stored.
+ * Shapes must allow the vector paths (channel counts multiples of 4, 8-byte aligned rows) unless stated.
+ * ================================================================================================== */
+
+/* Linear (modules/pointnet2_utils.py:413-418) on v_mfma_f32_32x32x16_bf16, fp32 accumulation:
+ *   C[M,N] = A[M,K] * op(B) (+ bias[N]);  A bf16 row-major (lda);
+ *   transB = 1: B stored [N][K] (nn.Linear.weight -- the forward product x W^T);
+ *   transB = 0: B stored [K][N] (the same weight walked along its rows: dX = dY W);
+ *   b_is_f32: B holds fp32 (the master parameters, converted while staged) instead of bf16;
+ *   c_is_f32: C receives fp32 (the logits handed to the loss) instead of bf16.
+ * tile_stats (optional): [ceil(M/64)][2][N] floats, the BatchNorm batch statistics of the UNROUNDED fp32
+ * results in the format mpa_bn_finalize_f32 consumes (see mpa_gemm_f32).  Any M, N, K; rows that are not
+ * 16-byte aligned take an element-wise path. */
+int mpa_gemm_bf16(const mpa_bf16 *A, int lda, const void *B, int ldb, int transB, int b_is_f32,
+                  const float *bias, void *C, int ldc, int c_is_f32, int M, int N, int K,
+                  float *tile_stats, void *stream);
+/* Grouped weight gradients on bf16 operands: out_p[M,N] (fp32) = A_p^T B_p, A_p [K][M] (lda), B_p [K][N] (ldb)
+ * bf16 -- dW = dY^T X of every Linear of a backward pass in one launch (+ one reduce launch); same contract
+ * as mpa_gemm_tn_grouped_f32 (a_col_sum optional, fp32, cleared by the caller; problems is a HOST array). */
+typedef struct MpaGemmTnProblemBf16 {
+    const mpa_bf16 *A;
+    const mpa_bf16 *B;
+    float *out;
+    float *a_col_sum;
+    int lda, ldb, M, N, K;
+} MpaGemmTnProblemBf16;
+int mpa_gemm_tn_grouped_bf16(const MpaGemmTnProblemBf16 *problems, int count, float *workspace,
+                             size_t workspace_bytes, void *stream);
+/* BatchNorm1d + LeakyReLU (+ residual) over bf16 rows; statistics, gamma / beta and their gradients fp32
+ * (mpa_bn_finalize_f32 is shared).  Same semantics as the _f32 entry points. */
+int mpa_bn_act_fwd_bf16(const mpa_bf16 *x, const float *save_mean_invstd, const float *gamma, const float *beta,
+                        const mpa_bf16 *residual, float slope, int M, int C, mpa_bf16 *y, void *stream);
+int mpa_bn_act_bwd_reduce_bf16(const mpa_bf16 *x, const mpa_bf16 *grad_y, const float *mean, const float *invstd,
+                               const float *gamma, const float *beta, float slope, int M, int C,
+                               int ldg, float *partial, int replicas, void *stream);
+int mpa_bn_act_bwd_apply_bf16(const mpa_bf16 *x, const mpa_bf16 *grad_y, const float *mean, const float *invstd,
+                              const float *gamma, const float *beta, const float *partial, int replicas,
+                              float slope, int use_batch_stats, int M, int C, int ldg, mpa_bf16 *grad_x,
+                              float *dgamma, float *dbeta, void *stream);
+/* index_points (:64-81) on bf16 rows.  Backward scatter-adds the bf16 gradient rows into an fp32
+ * accumulator (grad_points fp32, cleared by the caller): sums over duplicated indices stay fp32. */
+int mpa_gather_fwd_bf16(const mpa_bf16 *points, const int64_t *idx, int B, int N, int M, int C,
+                        mpa_bf16 *out, void *stream);
+int mpa_gather_bwd_bf16(const mpa_bf16 *grad_out, const int64_t *idx, int B, int N, int M, int C,
+                        float *grad_points, void *stream);
+/* difference-wise attention (:548-569) on bf16 q / k / v / ctx (softmax, offset and max in fp32 registers).
+ * Backward requires the workspace of mpa_diffattn_bwd_workspace_bytes_bf16() (per-slot key gradients are
+ * kept in bf16, summed per base row in fp32, stored bf16; never float atomics on bf16). */
+int mpa_diffattn_fwd_bf16(const mpa_bf16 *q, int ldq, const mpa_bf16 *k, const mpa_bf16 *v, int ldkv,
+                          const int64_t *idx, int B, int N, int S, int K, int C,
+                          mpa_bf16 *ctx, uint8_t *argk, void *stream);
+size_t mpa_diffattn_bwd_workspace_bytes_bf16(int B, int N, int S, int K, int C);
+int mpa_diffattn_bwd_bf16(const mpa_bf16 *q, int ldq, const mpa_bf16 *k, const mpa_bf16 *v, int ldkv,
+                          const int64_t *idx, const uint8_t *argk, const mpa_bf16 *grad_ctx,
+                          int B, int N, int S, int K, int C,
+                          mpa_bf16 *grad_q, mpa_bf16 *grad_k, mpa_bf16 *grad_v, int ldg,
+                          void *workspace, size_t workspace_bytes, void *stream);
+/* xyz branch (:518-544): coordinates and projection weights fp32, ctx (and its gradient) bf16 */
+int mpa_diffattn_xyz_fwd_bf16(const float *xyz, const float *center, const int64_t *idx,
+                              const float *Wq, const float *bq, const float *Wk, const float *bk,
+                              const float *Wv, const float *bv,
+                              int B, int N, int S, int K, int C,
+                              mpa_bf16 *ctx, uint8_t *argk, void *stream);
+int mpa_diffattn_xyz_bwd_bf16(const float *xyz, const float *center, const int64_t *idx,
+                              const float *Wq, const float *bq, const float *Wk, const float *bk,
+                              const float *Wv, const float *bv, const uint8_t *argk,
+                              const mpa_bf16 *grad_ctx, int B, int N, int S, int K, int C,
+                              float *gWq, float *gbq, float *gWk, float *gbk, float *gWv, float *gbv,
+                              void *stream);
+/* upsample (:13-50) on bf16 rows; the workspace of mpa_upsample_workspace_bytes() is required (the
+ * inverted-table gather; no atomic path on bf16).  cnt stays fp32. */
+int mpa_upsample_mean_fwd_bf16(const mpa_bf16 *points, const int64_t *knn_idx, int B, int S, int K,
+                               int Nf, int C, mpa_bf16 *out, float *cnt, void *workspace,
+                               size_t workspace_bytes, void *stream);
+int mpa_upsample_mean_bwd_bf16(const mpa_bf16 *grad_out, const int64_t *knn_idx, const float *cnt,
+                               int B, int S, int K, int Nf, int C, mpa_bf16 *grad_points,
+                               void *stream);
+/*BF16_MORE*/
 
 #ifdef __cplusplus
 }

@@ -66,11 +66,37 @@ class GemmTnProblem(ctypes.Structure):
 
 SIGNATURES["mpa_gemm_tn_grouped_f32"] = [ctypes.POINTER(GemmTnProblem), _i, _vp, ctypes.c_size_t, _vp]
 
+
+class GemmTnProblemBf16(ctypes.Structure):
+    """struct MpaGemmTnProblemBf16 of include/mpa_hip.h"""
+    _fields_ = [("A", _vp), ("B", _vp), ("out", _vp), ("a_col_sum", _vp),
+                ("lda", _i), ("ldb", _i), ("M", _i), ("N", _i), ("K", _i)]
+
+
+# ---- bf16 feature path (same argument order as the _f32 entry points unless noted)
+SIGNATURES.update({
+    "mpa_gemm_bf16": [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
+    "mpa_gemm_tn_grouped_bf16": [ctypes.POINTER(GemmTnProblemBf16), _i, _vp, ctypes.c_size_t, _vp],
+    "mpa_bn_act_fwd_bf16": SIGNATURES["mpa_bn_act_fwd_f32"],
+    "mpa_bn_act_bwd_reduce_bf16": SIGNATURES["mpa_bn_act_bwd_reduce_f32"],
+    "mpa_bn_act_bwd_apply_bf16": SIGNATURES["mpa_bn_act_bwd_apply_f32"],
+    "mpa_gather_fwd_bf16": SIGNATURES["mpa_gather_fwd_f32"],
+    "mpa_gather_bwd_bf16": SIGNATURES["mpa_gather_bwd_f32"],
+    "mpa_diffattn_fwd_bf16": SIGNATURES["mpa_diffattn_fwd_f32"],
+    "mpa_diffattn_bwd_bf16": SIGNATURES["mpa_diffattn_bwd_f32"],
+    "mpa_diffattn_bwd_workspace_bytes_bf16": SIGNATURES["mpa_diffattn_bwd_workspace_bytes"],
+    "mpa_diffattn_xyz_fwd_bf16": SIGNATURES["mpa_diffattn_xyz_fwd_f32"],
+    "mpa_diffattn_xyz_bwd_bf16": SIGNATURES["mpa_diffattn_xyz_bwd_f32"],
+    "mpa_upsample_mean_fwd_bf16": SIGNATURES["mpa_upsample_mean_fwd_f32"],
+    "mpa_upsample_mean_bwd_bf16": SIGNATURES["mpa_upsample_mean_bwd_f32"],
+})
+
 for _name, _args in SIGNATURES.items():
     _fn = getattr(lib, _name)
     _fn.argtypes = _args
     _fn.restype = ctypes.c_int
 lib.mpa_diffattn_bwd_workspace_bytes.restype = ctypes.c_size_t
+lib.mpa_diffattn_bwd_workspace_bytes_bf16.restype = ctypes.c_size_t
 lib.mpa_upsample_workspace_bytes.restype = ctypes.c_size_t
 lib.mpa_version.restype = ctypes.c_int
 lib.mpa_error_string.restype = ctypes.c_char_p

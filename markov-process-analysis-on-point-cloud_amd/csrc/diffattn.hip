@@ -11,7 +11,10 @@
 // Backward uses the closed form of SURVEY.md Appendix A8 and recomputes the softmax; it keeps
 // only the 1-byte arg-max from forward.
 #include "mpa_common.h"
+#include "mpa_bf16.h"
 #include "csr_build.h"
+#include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -87,12 +90,12 @@ __global__ __launch_bounds__(TPB) void diffattn_fwd_kernel(const float *__restri
 
 // float4 lanes: one lane owns 4 consecutive channels of a point, so every gathered row is read as
 // 16 B per lane (C % 4 == 0, 16-B aligned rows).
-template <int K_>
-__global__ __launch_bounds__(TPB) void diffattn_fwd_v4_kernel(const float *__restrict__ q, const float *__restrict__ kk,
-                                                              const float *__restrict__ vv, int ldkv, int ldq,
+template <int K_, typename T>
+__global__ __launch_bounds__(TPB) void diffattn_fwd_v4_kernel(const T *__restrict__ q, const T *__restrict__ kk,
+                                                              const T *__restrict__ vv, int ldkv, int ldq,
                                                               const int64_t *__restrict__ idx, int N, int S, int K,
                                                               int C, float alpha, long long total4,
-                                                              float *__restrict__ ctx, uint8_t *__restrict__ argk)
+                                                              T *__restrict__ ctx, uint8_t *__restrict__ argk)
 {
     constexpr int KK = K_ > 0 ? K_ : KMAX;
     const int k_ = K_ > 0 ? K_ : K;
@@ -102,15 +105,15 @@ __global__ __launch_bounds__(TPB) void diffattn_fwd_v4_kernel(const float *__res
         const int c = (int)(i - p * c4n) << 2;
         const int b = (int)(p / S);
         const int64_t *nb = idx + p * k_;
-        const float4 q4 = *reinterpret_cast<const float4 *>(q + p * ldq + c);
+        const float4 q4 = mpa_ld4<T>(q + p * ldq + c);
         const float qv[4] = {q4.x, q4.y, q4.z, q4.w};
         float4 k4[KK], v4[KK];
 #pragma unroll
         for (int j = 0; j < KK; ++j)
             if (j < k_) {
                 const long long row = ((long long)b * N + mpa_clamp_idx(nb[j], N)) * ldkv + c;
-                k4[j] = *reinterpret_cast<const float4 *>(kk + row);
-                v4[j] = *reinterpret_cast<const float4 *>(vv + row);
+                k4[j] = mpa_ld4<T>(kk + row);
+                v4[j] = mpa_ld4<T>(vv + row);
             }
         float best4[4];
         uint8_t bj4[4];
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(TPB) void diffattn_fwd_v4_kernel(const float *__res
             best4[u] = best;
             bj4[u] = (uint8_t)bj;
         }
-        *reinterpret_cast<float4 *>(ctx + p * C + c) = make_float4(best4[0], best4[1], best4[2], best4[3]);
+        mpa_st4<T>(ctx + p * C + c, make_float4(best4[0], best4[1], best4[2], best4[3]));
         *reinterpret_cast<uchar4 *>(argk + p * C + c) = make_uchar4(bj4[0], bj4[1], bj4[2], bj4[3]);
     }
 }
@@ -249,12 +252,12 @@ __global__ __launch_bounds__(TPB) void diffattn_bwd_p1_kernel(
     }
 }
 
-template <int K_>
+template <int K_, typename TF>
 __global__ __launch_bounds__(TPB) void diffattn_bwd_p1_v4_kernel(
-    const float *__restrict__ q, const float *__restrict__ kk, const float *__restrict__ vv, int ldkv, int ldq,
-    const int64_t *__restrict__ idx, const uint8_t *__restrict__ argk, const float *__restrict__ gctx, int N, int S,
-    int K, int C, float alpha, long long total4, float *__restrict__ gq, float *__restrict__ T,
-    float *__restrict__ Tv)
+    const TF *__restrict__ q, const TF *__restrict__ kk, const TF *__restrict__ vv, int ldkv, int ldq,
+    const int64_t *__restrict__ idx, const uint8_t *__restrict__ argk, const TF *__restrict__ gctx, int N, int S,
+    int K, int C, float alpha, long long total4, TF *__restrict__ gq, TF *__restrict__ T,
+    TF *__restrict__ Tv)
 {
     constexpr int KK = K_ > 0 ? K_ : KMAX;
     const int k_ = K_ > 0 ? K_ : K;
@@ -264,8 +267,8 @@ __global__ __launch_bounds__(TPB) void diffattn_bwd_p1_v4_kernel(
         const int c = (int)(i - p * c4n) << 2;
         const int b = (int)(p / S);
         const int64_t *nb = idx + p * k_;
-        const float4 q4 = *reinterpret_cast<const float4 *>(q + p * ldq + c);
-        const float4 g4 = *reinterpret_cast<const float4 *>(gctx + p * C + c);
+        const float4 q4 = mpa_ld4<TF>(q + p * ldq + c);
+        const float4 g4 = mpa_ld4<TF>(gctx + p * C + c);
         const uchar4 ks4 = *reinterpret_cast<const uchar4 *>(argk + p * C + c);
         const float qv[4] = {q4.x, q4.y, q4.z, q4.w}, gv_[4] = {g4.x, g4.y, g4.z, g4.w};
         const int ks[4] = {ks4.x, ks4.y, ks4.z, ks4.w};
@@ -275,7 +278,7 @@ __global__ __launch_bounds__(TPB) void diffattn_bwd_p1_v4_kernel(
         for (int j = 0; j < KK; ++j)
             if (j < k_) {
                 rows[j] = ((long long)b * N + mpa_clamp_idx(nb[j], N)) * ldkv + c;
-                k4[j] = *reinterpret_cast<const float4 *>(kk + rows[j]);
+                k4[j] = mpa_ld4<TF>(kk + rows[j]);
             }
         float vstar[4];
 #pragma unroll
@@ -284,7 +287,7 @@ __global__ __launch_bounds__(TPB) void diffattn_bwd_p1_v4_kernel(
 #pragma unroll
             for (int j = 1; j < KK; ++j)
                 if (j < k_ && j == ks[u]) r = rows[j];
-            vstar[u] = vv[r + u];
+            vstar[u] = mpa_ld1<TF>(vv + r + u);
         }
         float de[KK][4], dq4[4], dv4[4];
 #pragma unroll
@@ -312,13 +315,12 @@ __global__ __launch_bounds__(TPB) void diffattn_bwd_p1_v4_kernel(
             dq4[u] = alpha * dq;
             dv4[u] = gv_[u] * (astar - o);
         }
-        float *Tp = T + p * k_ * C + c;
+        TF *Tp = T + p * k_ * C + c;
 #pragma unroll
         for (int j = 0; j < KK; ++j)
-            if (j < k_)
-                *reinterpret_cast<float4 *>(Tp + (long long)j * C) = make_float4(de[j][0], de[j][1], de[j][2], de[j][3]);
-        *reinterpret_cast<float4 *>(gq + p * ldq + c) = make_float4(dq4[0], dq4[1], dq4[2], dq4[3]);
-        *reinterpret_cast<float4 *>(Tv + p * C + c) = make_float4(dv4[0], dv4[1], dv4[2], dv4[3]);
+            if (j < k_) mpa_st4<TF>(Tp + (long long)j * C, make_float4(de[j][0], de[j][1], de[j][2], de[j][3]));
+        mpa_st4<TF>(gq + p * ldq + c, make_float4(dq4[0], dq4[1], dq4[2], dq4[3]));
+        mpa_st4<TF>(Tv + p * C + c, make_float4(dv4[0], dv4[1], dv4[2], dv4[3]));
     }
 }
 
@@ -330,11 +332,11 @@ __global__ __launch_bounds__(TPB) void diffattn_bwd_p1_v4_kernel(
 // while the rest of the chip waits (420 us instead of 20 us per launch in the part-seg decoder).
 constexpr int P2_LONG = 48;
 
-template <int V>
+template <int V, typename TF>
 __global__ __launch_bounds__(TPB) void diffattn_bwd_p2_kernel(
-    const float *__restrict__ T, const float *__restrict__ Tv, const uint8_t *__restrict__ argk,
+    const TF *__restrict__ T, const TF *__restrict__ Tv, const uint8_t *__restrict__ argk,
     const int *__restrict__ rowptr, const int *__restrict__ entries, int N, int S, int K, int C, int lanes_per_row,
-    float *__restrict__ gk, float *__restrict__ gv, int ldg)
+    TF *__restrict__ gk, TF *__restrict__ gv, int ldg)
 {
     __shared__ int long_rows[TPB];
     __shared__ int n_long;
@@ -345,8 +347,8 @@ __global__ __launch_bounds__(TPB) void diffattn_bwd_p2_kernel(
     const int r = blockIdx.x * rpb + rl;
     const int *rp = rowptr + (size_t)b * (N + 1);
     const int *en = entries + (size_t)b * S * K;
-    const float *Tb = T + (size_t)b * S * K * C;
-    const float *Tvb = Tv + (size_t)b * S * C;
+    const TF *Tb = T + (size_t)b * S * K * C;
+    const TF *Tvb = Tv + (size_t)b * S * C;
     const uint8_t *ab = argk + (size_t)b * S * C;
     if (threadIdx.x == 0) n_long = 0;
     __syncthreads();
@@ -355,29 +357,29 @@ __global__ __launch_bounds__(TPB) void diffattn_bwd_p2_kernel(
     auto add_entry = [&](unsigned ent, int c, float (&ak)[V], float (&av)[V]) {
         const unsigned s_ = ent / (unsigned)K, j = ent - s_ * (unsigned)K;
         if constexpr (V == 4) {
-            const float4 t = *reinterpret_cast<const float4 *>(Tb + (ent * (unsigned)C + (unsigned)c));
+            const float4 t = mpa_ld4<TF>(Tb + (ent * (unsigned)C + (unsigned)c));
             const uchar4 am = *reinterpret_cast<const uchar4 *>(ab + (s_ * (unsigned)C + (unsigned)c));
             ak[0] += t.x; ak[1] += t.y; ak[2] += t.z; ak[3] += t.w;
             if (am.x == j || am.y == j || am.z == j || am.w == j) {
-                const float4 d = *reinterpret_cast<const float4 *>(Tvb + (s_ * (unsigned)C + (unsigned)c));
+                const float4 d = mpa_ld4<TF>(Tvb + (s_ * (unsigned)C + (unsigned)c));
                 if (am.x == j) av[0] += d.x;
                 if (am.y == j) av[1] += d.y;
                 if (am.z == j) av[2] += d.z;
                 if (am.w == j) av[3] += d.w;
             }
         } else {
-            ak[0] += Tb[ent * (unsigned)C + (unsigned)c];
-            if (ab[s_ * (unsigned)C + (unsigned)c] == j) av[0] += Tvb[s_ * (unsigned)C + (unsigned)c];
+            ak[0] += mpa_ld1<TF>(Tb + (ent * (unsigned)C + (unsigned)c));
+            if (ab[s_ * (unsigned)C + (unsigned)c] == j) av[0] += mpa_ld1<TF>(Tvb + (s_ * (unsigned)C + (unsigned)c));
         }
     };
     auto store_row = [&](int row, int c, const float (&ak)[V], const float (&av)[V]) {
-        float *ok = gk + ((size_t)b * N + row) * ldg + c, *ov = gv + ((size_t)b * N + row) * ldg + c;
+        TF *ok = gk + ((size_t)b * N + row) * ldg + c, *ov = gv + ((size_t)b * N + row) * ldg + c;
         if constexpr (V == 4) {
-            *reinterpret_cast<float4 *>(ok) = make_float4(ak[0], ak[1], ak[2], ak[3]);
-            *reinterpret_cast<float4 *>(ov) = make_float4(av[0], av[1], av[2], av[3]);
+            mpa_st4<TF>(ok, make_float4(ak[0], ak[1], ak[2], ak[3]));
+            mpa_st4<TF>(ov, make_float4(av[0], av[1], av[2], av[3]));
         } else {
-            ok[0] = ak[0];
-            ov[0] = av[0];
+            mpa_st1<TF>(ok, ak[0]);
+            mpa_st1<TF>(ov, av[0]);
         }
     };
 
@@ -399,7 +401,7 @@ __global__ __launch_bounds__(TPB) void diffattn_bwd_p2_kernel(
                         uchar4 am[4];
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {                  // four rows of T in flight together
-                            t[u] = *reinterpret_cast<const float4 *>(Tb + (ent[u] * (unsigned)C + (unsigned)c));
+                            t[u] = mpa_ld4<TF>(Tb + (ent[u] * (unsigned)C + (unsigned)c));
                             am[u] = *reinterpret_cast<const uchar4 *>(ab + ((ent[u] / (unsigned)K) * (unsigned)C + (unsigned)c));
                         }
 #pragma unroll
@@ -408,7 +410,7 @@ __global__ __launch_bounds__(TPB) void diffattn_bwd_p2_kernel(
                             ak[0] += t[u].x; ak[1] += t[u].y; ak[2] += t[u].z; ak[3] += t[u].w;
                             const unsigned s_ = ent[u] / (unsigned)K, j = ent[u] - s_ * (unsigned)K;
                             if (am[u].x == j || am[u].y == j || am[u].z == j || am[u].w == j) {
-                                const float4 d = *reinterpret_cast<const float4 *>(Tvb + (s_ * (unsigned)C + (unsigned)c));
+                                const float4 d = mpa_ld4<TF>(Tvb + (s_ * (unsigned)C + (unsigned)c));
                                 if (am[u].x == j) av[0] += d.x;
                                 if (am[u].y == j) av[1] += d.y;
                                 if (am[u].z == j) av[2] += d.z;
@@ -466,12 +468,12 @@ __global__ __launch_bounds__(TPB) void diffattn_bwd_p2_kernel(
 // ------------------------------------------------------------------ xyz branch
 // One lane = one output channel with its 12 projection weights in registers; the workgroup
 // walks points, whose centre / neighbour coordinates are wave-uniform.
-template <int K_>
+template <int K_, typename TF>
 __global__ __launch_bounds__(TPB) void diffattn_xyz_fwd_kernel(
     const float *__restrict__ xyz, const float *__restrict__ center, const int64_t *__restrict__ idx,
     const float *__restrict__ Wq, const float *__restrict__ bq, const float *__restrict__ Wk,
     const float *__restrict__ bk, const float *__restrict__ Wv, const float *__restrict__ bv, int N, int S, int K,
-    int C, float alpha, long long npoints, float *__restrict__ ctx, uint8_t *__restrict__ argk)
+    int C, float alpha, long long npoints, TF *__restrict__ ctx, uint8_t *__restrict__ argk)
 {
     const int k_ = K_ > 0 ? K_ : K;
     const int c = blockIdx.y * blockDim.x + threadIdx.x;
@@ -504,7 +506,7 @@ __global__ __launch_bounds__(TPB) void diffattn_xyz_fwd_kernel(
                 float t = (a[j] - o) * v[j];
                 if (t > best) { best = t; bj = j; }
             }
-        ctx[p * C + c] = best;
+        mpa_st1<TF>(ctx + p * C + c, best);
         argk[p * C + c] = (uint8_t)bj;
     }
 }
@@ -512,12 +514,12 @@ __global__ __launch_bounds__(TPB) void diffattn_xyz_fwd_kernel(
 // Workgroup = PW point-lanes x bx channel-lanes (1024 threads): each point-lane walks points, a
 // lane keeps its channel's 18 partial gradients in registers; they meet in LDS (ds_add_f32) and
 // leave as one global atomic per (workgroup, value).
-template <int K_>
+template <int K_, typename TF>
 __global__ __launch_bounds__(BWD_TPB) void diffattn_xyz_bwd_kernel(
     const float *__restrict__ xyz, const float *__restrict__ center, const int64_t *__restrict__ idx,
     const float *__restrict__ Wq, const float *__restrict__ bq, const float *__restrict__ Wk,
     const float *__restrict__ bk, const float *__restrict__ Wv, const float *__restrict__ bv,
-    const uint8_t *__restrict__ argk, const float *__restrict__ gctx, int N, int S, int K, int C, int bx,
+    const uint8_t *__restrict__ argk, const TF *__restrict__ gctx, int N, int S, int K, int C, int bx,
     float alpha, long long npoints, float *__restrict__ gWq, float *__restrict__ gbq, float *__restrict__ gWk,
     float *__restrict__ gbk, float *__restrict__ gWv, float *__restrict__ gbv)
 {
@@ -539,7 +541,7 @@ __global__ __launch_bounds__(BWD_TPB) void diffattn_xyz_bwd_kernel(
         const float qv = fmaf(wq2, cz, fmaf(wq1, cy, fmaf(wq0, cx, bqc)));
         const int64_t *nb = idx + p * k_;
         const int ks = argk[p * C + cc];
-        const float g = gctx[p * C + cc];
+        const float g = mpa_ld1<TF>(gctx + p * C + cc);
         float e[K_ > 0 ? K_ : KMAX], a[K_ > 0 ? K_ : KMAX];
         float rx[K_ > 0 ? K_ : KMAX], ry[K_ > 0 ? K_ : KMAX], rz[K_ > 0 ? K_ : KMAX];
         float vstar = 0.f, sx = 0.f, sy = 0.f, sz = 0.f;
@@ -609,59 +611,180 @@ inline int grid_for(long long total)
     return (int)(g > 16384 ? 16384 : (g < 1 ? 1 : g));
 }
 
+// rows x C floats with leading dimension ld, two tensors at once.  A plain kernel instead of hipMemset2DAsync:
+// inside a captured HIP graph the clear is an ordinary kernel node (no memset nodes anywhere on the path).
+__global__ void clear2_strided_kernel(float *__restrict__ a, float *__restrict__ b, long long rows, int C, int ld)
+{
+    const long long total = rows * C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / C;
+        const int c = (int)(i - r * C);
+        a[r * ld + c] = 0.f;
+        b[r * ld + c] = 0.f;
+    }
+}
+
 }  // namespace
 
-extern "C" int mpa_diffattn_fwd_f32(const float *q, int ldq, const float *k, const float *v, int ldkv,
-                                    const int64_t *idx, int B, int N, int S, int K, int C, float *ctx, uint8_t *argk,
-                                    void *stream)
+template <typename TF>
+static int diffattn_fwd_any(const TF *q, int ldq, const TF *k, const TF *v, int ldkv, const int64_t *idx, int B, int N,
+                            int S, int K, int C, TF *ctx, uint8_t *argk, void *stream)
 {
     MPA_CLEAR_ERROR();
     if (!q || !k || !v || !idx || !ctx || !argk || B <= 0 || N <= 0 || S <= 0 || K <= 0 || C <= 0 || ldkv < C ||
         ldq < C)
         return MPA_EINVAL;
     if (K > KMAX) return MPA_EUNSUPPORTED;
+    constexpr bool F32 = std::is_same<TF, float>::value;
     long long total = (long long)B * S * C;
     float alpha = 1.0f / sqrtf((float)C);
     hipStream_t st = (hipStream_t)stream;
     static const bool scalar_only = getenv("MPA_DIFFATTN_SCALAR") != nullptr;
-    const bool vec4 = !scalar_only && (C & 3) == 0 && (ldkv & 3) == 0 && (ldq & 3) == 0 &&
-                      ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)ctx | (uintptr_t)argk)) & 15) == 0;
+    const bool vec4 = (!scalar_only || !F32) && (C & 3) == 0 && (ldkv & 3) == 0 && (ldq & 3) == 0 &&
+                      ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)ctx) & mpa_vec4_align<TF>::mask) == 0) &&
+                      (((uintptr_t)argk & 3) == 0);
     if (vec4 && K == 8)
-        hipLaunchKernelGGL(diffattn_fwd_v4_kernel<8>, dim3(grid_for(total / 4)), dim3(TPB), 0, st, q, k, v, ldkv, ldq, idx,
-                           N, S, K, C, alpha, total / 4, ctx, argk);
-    else if (K == 8)
-        hipLaunchKernelGGL(diffattn_fwd_kernel<8>, dim3(grid_for(total)), dim3(TPB), 0, st, q, k, v, ldkv, ldq, idx, N, S,
-                           K, C, alpha, total, ctx, argk);
-    else
-        hipLaunchKernelGGL(diffattn_fwd_kernel<0>, dim3(grid_for(total)), dim3(TPB), 0, st, q, k, v, ldkv, ldq, idx, N, S,
-                           K, C, alpha, total, ctx, argk);
+        hipLaunchKernelGGL((diffattn_fwd_v4_kernel<8, TF>), dim3(grid_for(total / 4)), dim3(TPB), 0, st, q, k, v, ldkv, ldq,
+                           idx, N, S, K, C, alpha, total / 4, ctx, argk);
+    else if (vec4)
+        hipLaunchKernelGGL((diffattn_fwd_v4_kernel<0, TF>), dim3(grid_for(total / 4)), dim3(TPB), 0, st, q, k, v, ldkv, ldq,
+                           idx, N, S, K, C, alpha, total / 4, ctx, argk);
+    else if constexpr (F32) {
+        if (K == 8)
+            hipLaunchKernelGGL(diffattn_fwd_kernel<8>, dim3(grid_for(total)), dim3(TPB), 0, st, q, k, v, ldkv, ldq, idx, N,
+                               S, K, C, alpha, total, ctx, argk);
+        else
+            hipLaunchKernelGGL(diffattn_fwd_kernel<0>, dim3(grid_for(total)), dim3(TPB), 0, st, q, k, v, ldkv, ldq, idx, N,
+                               S, K, C, alpha, total, ctx, argk);
+    } else {
+        return MPA_EUNSUPPORTED;            // bf16 rows: 4-channel lanes only (C % 4 == 0, 8-byte aligned rows)
+    }
     MPA_LAUNCH_CHECK();
     return MPA_OK;
+}
+
+extern "C" int mpa_diffattn_fwd_f32(const float *q, int ldq, const float *k, const float *v, int ldkv,
+                                    const int64_t *idx, int B, int N, int S, int K, int C, float *ctx, uint8_t *argk,
+                                    void *stream)
+{
+    return diffattn_fwd_any<float>(q, ldq, k, v, ldkv, idx, B, N, S, K, C, ctx, argk, stream);
+}
+
+extern "C" int mpa_diffattn_fwd_bf16(const mpa_bf16 *q, int ldq, const mpa_bf16 *k, const mpa_bf16 *v, int ldkv,
+                                     const int64_t *idx, int B, int N, int S, int K, int C, mpa_bf16 *ctx,
+                                     uint8_t *argk, void *stream)
+{
+    return diffattn_fwd_any<bf16_t>(reinterpret_cast<const bf16_t *>(q), ldq, reinterpret_cast<const bf16_t *>(k),
+                                    reinterpret_cast<const bf16_t *>(v), ldkv, idx, B, N, S, K, C,
+                                    reinterpret_cast<bf16_t *>(ctx), argk, stream);
 }
 
 namespace {
 struct BwdWorkspace {
     size_t t_off, tv_off, rowptr_off, entries_off, total;
 };
-inline BwdWorkspace bwd_workspace(int B, int N, int S, int K, int C)
+inline BwdWorkspace bwd_workspace(int B, int N, int S, int K, int C, size_t esz)
 {
     BwdWorkspace w;
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     w.t_off = 0;
-    w.tv_off = up((size_t)B * S * K * C * 4);
-    w.rowptr_off = w.tv_off + up((size_t)B * S * C * 4);
+    w.tv_off = up((size_t)B * S * K * C * esz);
+    w.rowptr_off = w.tv_off + up((size_t)B * S * C * esz);
     w.entries_off = w.rowptr_off + up((size_t)B * (N + 1) * 4);
     w.total = w.entries_off + up((size_t)B * S * K * 4);
     return w;
+}
+inline bool bwd_workspace_ok(int B, int N, int S, int K, int C)
+{
+    return !(B <= 0 || N <= 0 || S <= 0 || K <= 0 || C <= 0 || N > CSR_MAX_N || (long long)S * K * C > 0x7fffffffLL ||
+             B > 65535);
 }
 }  // namespace
 
 extern "C" size_t mpa_diffattn_bwd_workspace_bytes(int B, int N, int S, int K, int C)
 {
-    if (B <= 0 || N <= 0 || S <= 0 || K <= 0 || C <= 0 || N > CSR_MAX_N || (long long)S * K * C > 0x7fffffffLL ||
-        B > 65535)
-        return 0;
-    return bwd_workspace(B, N, S, K, C).total;
+    return bwd_workspace_ok(B, N, S, K, C) ? bwd_workspace(B, N, S, K, C, 4).total : 0;
+}
+
+extern "C" size_t mpa_diffattn_bwd_workspace_bytes_bf16(int B, int N, int S, int K, int C)
+{
+    return bwd_workspace_ok(B, N, S, K, C) ? bwd_workspace(B, N, S, K, C, 2).total : 0;
+}
+
+template <typename TF>
+static int diffattn_bwd_any(const TF *q, int ldq, const TF *k, const TF *v, int ldkv, const int64_t *idx,
+                            const uint8_t *argk, const TF *grad_ctx, int B, int N, int S, int K, int C, TF *grad_q,
+                            TF *grad_k, TF *grad_v, int ldg, void *workspace, size_t workspace_bytes, void *stream)
+{
+    MPA_CLEAR_ERROR();
+    if (!q || !k || !v || !idx || !argk || !grad_ctx || !grad_q || !grad_k || !grad_v || B <= 0 || N <= 0 || S <= 0 ||
+        K <= 0 || C <= 0 || ldkv < C || ldg < C || ldq < C)
+        return MPA_EINVAL;
+    if (K > KMAX) return MPA_EUNSUPPORTED;
+    constexpr bool F32 = std::is_same<TF, float>::value;
+    long long total = (long long)B * S * C;
+    float alpha = 1.0f / sqrtf((float)C);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t need = bwd_workspace_ok(B, N, S, K, C) ? bwd_workspace(B, N, S, K, C, sizeof(TF)).total : 0;
+    static const bool force_atomic = getenv("MPA_DIFFATTN_ATOMIC") != nullptr;
+    if (workspace && need && workspace_bytes >= need && ((uintptr_t)workspace & 15) == 0 && !(force_atomic && F32)) {
+        const BwdWorkspace w = bwd_workspace(B, N, S, K, C, sizeof(TF));
+        TF *T = reinterpret_cast<TF *>((char *)workspace + w.t_off);
+        TF *Tv = reinterpret_cast<TF *>((char *)workspace + w.tv_off);
+        int *rowptr = reinterpret_cast<int *>((char *)workspace + w.rowptr_off);
+        int *entries = reinterpret_cast<int *>((char *)workspace + w.entries_off);
+        launch_csr_build(idx, B, N, S * K, rowptr, entries, st);
+        static const bool scalar_only = getenv("MPA_DIFFATTN_SCALAR") != nullptr;
+        const bool p1v4 = (!scalar_only || !F32) && (C & 3) == 0 && (ldkv & 3) == 0 && (ldq & 3) == 0 &&
+                          ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)grad_ctx | (uintptr_t)grad_q) &
+                            mpa_vec4_align<TF>::mask) == 0) && (((uintptr_t)argk & 3) == 0);
+        if (p1v4 && K == 8)
+            hipLaunchKernelGGL((diffattn_bwd_p1_v4_kernel<8, TF>), dim3(grid_for(total / 4)), dim3(TPB), 0, st, q, k, v, ldkv,
+                               ldq, idx, argk, grad_ctx, N, S, K, C, alpha, total / 4, grad_q, T, Tv);
+        else if (p1v4)
+            hipLaunchKernelGGL((diffattn_bwd_p1_v4_kernel<0, TF>), dim3(grid_for(total / 4)), dim3(TPB), 0, st, q, k, v, ldkv,
+                               ldq, idx, argk, grad_ctx, N, S, K, C, alpha, total / 4, grad_q, T, Tv);
+        else if constexpr (F32) {
+            if (K == 8)
+                hipLaunchKernelGGL(diffattn_bwd_p1_kernel<8>, dim3(grid_for(total)), dim3(TPB), 0, st, q, k, v, ldkv, ldq,
+                                   idx, argk, grad_ctx, N, S, K, C, alpha, total, grad_q, T, Tv);
+            else
+                hipLaunchKernelGGL(diffattn_bwd_p1_kernel<0>, dim3(grid_for(total)), dim3(TPB), 0, st, q, k, v, ldkv, ldq,
+                                   idx, argk, grad_ctx, N, S, K, C, alpha, total, grad_q, T, Tv);
+        } else {
+            return MPA_EUNSUPPORTED;
+        }
+        const bool v4 = (C & 3) == 0 && (ldg & 3) == 0 &&
+                        ((((uintptr_t)grad_k | (uintptr_t)grad_v) & mpa_vec4_align<TF>::mask) == 0);
+        const int per = v4 ? C / 4 : C;
+        int lanes = 1;
+        while (lanes < per && lanes < TPB) lanes <<= 1;                     // power of two: divides 256
+        const dim3 grid2(mpa_ceil_div(N, TPB / lanes), B);
+        if (v4)
+            hipLaunchKernelGGL((diffattn_bwd_p2_kernel<4, TF>), grid2, dim3(TPB), 0, st, T, Tv, argk, rowptr, entries, N, S,
+                               K, C, lanes, grad_k, grad_v, ldg);
+        else
+            hipLaunchKernelGGL((diffattn_bwd_p2_kernel<1, TF>), grid2, dim3(TPB), 0, st, T, Tv, argk, rowptr, entries, N, S,
+                               K, C, lanes, grad_k, grad_v, ldg);
+        MPA_LAUNCH_CHECK();
+        return MPA_OK;
+    }
+    if constexpr (!F32) {
+        return MPA_EUNSUPPORTED;            // bf16 gradients are never accumulated with atomics: the workspace is required
+    } else {
+        // global-atomic kernel: clears the outputs first (grad_k | grad_v rows of C floats, stride ldg)
+        hipLaunchKernelGGL(clear2_strided_kernel, dim3(grid_for((long long)B * N * C)), dim3(TPB), 0, st, grad_k, grad_v,
+                           (long long)B * N, C, ldg);
+        if (K == 8)
+            hipLaunchKernelGGL(diffattn_bwd_kernel<8>, dim3(grid_for(total)), dim3(TPB), 0, st, q, k, v, ldkv, ldq, idx, argk,
+                               grad_ctx, N, S, K, C, alpha, total, grad_q, grad_k, grad_v, ldg);
+        else
+            hipLaunchKernelGGL(diffattn_bwd_kernel<0>, dim3(grid_for(total)), dim3(TPB), 0, st, q, k, v, ldkv, ldq, idx, argk,
+                               grad_ctx, N, S, K, C, alpha, total, grad_q, grad_k, grad_v, ldg);
+        MPA_LAUNCH_CHECK();
+        return MPA_OK;
+    }
 }
 
 extern "C" int mpa_diffattn_bwd_f32(const float *q, int ldq, const float *k, const float *v, int ldkv,
@@ -669,70 +792,26 @@ extern "C" int mpa_diffattn_bwd_f32(const float *q, int ldq, const float *k, con
                                     int K, int C, float *grad_q, float *grad_k, float *grad_v, int ldg, void *workspace,
                                     size_t workspace_bytes, void *stream)
 {
-    MPA_CLEAR_ERROR();
-    if (!q || !k || !v || !idx || !argk || !grad_ctx || !grad_q || !grad_k || !grad_v || B <= 0 || N <= 0 || S <= 0 ||
-        K <= 0 || C <= 0 || ldkv < C || ldg < C || ldq < C)
-        return MPA_EINVAL;
-    if (K > KMAX) return MPA_EUNSUPPORTED;
-    long long total = (long long)B * S * C;
-    float alpha = 1.0f / sqrtf((float)C);
-    hipStream_t st = (hipStream_t)stream;
-    const size_t need = mpa_diffattn_bwd_workspace_bytes(B, N, S, K, C);
-    static const bool force_atomic = getenv("MPA_DIFFATTN_ATOMIC") != nullptr;
-    if (workspace && need && workspace_bytes >= need && ((uintptr_t)workspace & 15) == 0 && !force_atomic) {
-        const BwdWorkspace w = bwd_workspace(B, N, S, K, C);
-        float *T = reinterpret_cast<float *>((char *)workspace + w.t_off);
-        float *Tv = reinterpret_cast<float *>((char *)workspace + w.tv_off);
-        int *rowptr = reinterpret_cast<int *>((char *)workspace + w.rowptr_off);
-        int *entries = reinterpret_cast<int *>((char *)workspace + w.entries_off);
-        launch_csr_build(idx, B, N, S * K, rowptr, entries, st);
-        static const bool scalar_only = getenv("MPA_DIFFATTN_SCALAR") != nullptr;
-        const bool p1v4 = !scalar_only && (C & 3) == 0 && (ldkv & 3) == 0 && (ldq & 3) == 0 &&
-                          ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)grad_ctx | (uintptr_t)grad_q |
-                             (uintptr_t)argk)) & 15) == 0;
-        if (p1v4 && K == 8)
-            hipLaunchKernelGGL(diffattn_bwd_p1_v4_kernel<8>, dim3(grid_for(total / 4)), dim3(TPB), 0, st, q, k, v, ldkv,
-                               ldq, idx, argk, grad_ctx, N, S, K, C, alpha, total / 4, grad_q, T, Tv);
-        else if (K == 8)
-            hipLaunchKernelGGL(diffattn_bwd_p1_kernel<8>, dim3(grid_for(total)), dim3(TPB), 0, st, q, k, v, ldkv, ldq, idx,
-                               argk, grad_ctx, N, S, K, C, alpha, total, grad_q, T, Tv);
-        else
-            hipLaunchKernelGGL(diffattn_bwd_p1_kernel<0>, dim3(grid_for(total)), dim3(TPB), 0, st, q, k, v, ldkv, ldq, idx,
-                               argk, grad_ctx, N, S, K, C, alpha, total, grad_q, T, Tv);
-        const bool v4 = (C & 3) == 0 && (ldg & 3) == 0 && ((((uintptr_t)grad_k | (uintptr_t)grad_v)) & 15) == 0;
-        const int per = v4 ? C / 4 : C;
-        int lanes = 1;
-        while (lanes < per && lanes < TPB) lanes <<= 1;                     // power of two: divides 256
-        const dim3 grid2(mpa_ceil_div(N, TPB / lanes), B);
-        if (v4)
-            hipLaunchKernelGGL(diffattn_bwd_p2_kernel<4>, grid2, dim3(TPB), 0, st, T, Tv, argk, rowptr, entries, N, S, K,
-                               C, lanes, grad_k, grad_v, ldg);
-        else
-            hipLaunchKernelGGL(diffattn_bwd_p2_kernel<1>, grid2, dim3(TPB), 0, st, T, Tv, argk, rowptr, entries, N, S, K,
-                               C, lanes, grad_k, grad_v, ldg);
-        MPA_LAUNCH_CHECK();
-        return MPA_OK;
-    }
-    // global-atomic kernel: clears the outputs first (grad_k | grad_v rows of C floats, stride ldg)
-    if (hipMemset2DAsync(grad_k, (size_t)ldg * 4, 0, (size_t)C * 4, (size_t)B * N, st) != hipSuccess ||
-        hipMemset2DAsync(grad_v, (size_t)ldg * 4, 0, (size_t)C * 4, (size_t)B * N, st) != hipSuccess) {
-        MPA_LAUNCH_CHECK();
-        return MPA_EHIP;
-    }
-    if (K == 8)
-        hipLaunchKernelGGL(diffattn_bwd_kernel<8>, dim3(grid_for(total)), dim3(TPB), 0, st, q, k, v, ldkv, ldq, idx, argk,
-                           grad_ctx, N, S, K, C, alpha, total, grad_q, grad_k, grad_v, ldg);
-    else
-        hipLaunchKernelGGL(diffattn_bwd_kernel<0>, dim3(grid_for(total)), dim3(TPB), 0, st, q, k, v, ldkv, ldq, idx, argk,
-                           grad_ctx, N, S, K, C, alpha, total, grad_q, grad_k, grad_v, ldg);
-    MPA_LAUNCH_CHECK();
-    return MPA_OK;
+    return diffattn_bwd_any<float>(q, ldq, k, v, ldkv, idx, argk, grad_ctx, B, N, S, K, C, grad_q, grad_k, grad_v, ldg,
+                                   workspace, workspace_bytes, stream);
 }
 
-extern "C" int mpa_diffattn_xyz_fwd_f32(const float *xyz, const float *center, const int64_t *idx, const float *Wq,
-                                        const float *bq, const float *Wk, const float *bk, const float *Wv,
-                                        const float *bv, int B, int N, int S, int K, int C, float *ctx, uint8_t *argk,
-                                        void *stream)
+extern "C" int mpa_diffattn_bwd_bf16(const mpa_bf16 *q, int ldq, const mpa_bf16 *k, const mpa_bf16 *v, int ldkv,
+                                     const int64_t *idx, const uint8_t *argk, const mpa_bf16 *grad_ctx, int B, int N,
+                                     int S, int K, int C, mpa_bf16 *grad_q, mpa_bf16 *grad_k, mpa_bf16 *grad_v, int ldg,
+                                     void *workspace, size_t workspace_bytes, void *stream)
+{
+    return diffattn_bwd_any<bf16_t>(reinterpret_cast<const bf16_t *>(q), ldq, reinterpret_cast<const bf16_t *>(k),
+                                    reinterpret_cast<const bf16_t *>(v), ldkv, idx, argk,
+                                    reinterpret_cast<const bf16_t *>(grad_ctx), B, N, S, K, C,
+                                    reinterpret_cast<bf16_t *>(grad_q), reinterpret_cast<bf16_t *>(grad_k),
+                                    reinterpret_cast<bf16_t *>(grad_v), ldg, workspace, workspace_bytes, stream);
+}
+
+template <typename TF>
+static int diffattn_xyz_fwd_any(const float *xyz, const float *center, const int64_t *idx, const float *Wq,
+                                const float *bq, const float *Wk, const float *bk, const float *Wv, const float *bv,
+                                int B, int N, int S, int K, int C, TF *ctx, uint8_t *argk, void *stream)
 {
     MPA_CLEAR_ERROR();
     if (!xyz || !center || !idx || !Wq || !bq || !Wk || !bk || !Wv || !bv || !ctx || !argk || B <= 0 || N <= 0 ||
@@ -745,20 +824,37 @@ extern "C" int mpa_diffattn_xyz_fwd_f32(const float *xyz, const float *center, c
     float alpha = 1.0f / sqrtf((float)C);
     hipStream_t st = (hipStream_t)stream;
     if (K == 8)
-        hipLaunchKernelGGL(diffattn_xyz_fwd_kernel<8>, grid, dim3(bx), 0, st, xyz, center, idx, Wq, bq, Wk, bk, Wv, bv, N,
-                           S, K, C, alpha, np, ctx, argk);
+        hipLaunchKernelGGL((diffattn_xyz_fwd_kernel<8, TF>), grid, dim3(bx), 0, st, xyz, center, idx, Wq, bq, Wk, bk, Wv, bv,
+                           N, S, K, C, alpha, np, ctx, argk);
     else
-        hipLaunchKernelGGL(diffattn_xyz_fwd_kernel<0>, grid, dim3(bx), 0, st, xyz, center, idx, Wq, bq, Wk, bk, Wv, bv, N,
-                           S, K, C, alpha, np, ctx, argk);
+        hipLaunchKernelGGL((diffattn_xyz_fwd_kernel<0, TF>), grid, dim3(bx), 0, st, xyz, center, idx, Wq, bq, Wk, bk, Wv, bv,
+                           N, S, K, C, alpha, np, ctx, argk);
     MPA_LAUNCH_CHECK();
     return MPA_OK;
 }
 
-extern "C" int mpa_diffattn_xyz_bwd_f32(const float *xyz, const float *center, const int64_t *idx, const float *Wq,
+extern "C" int mpa_diffattn_xyz_fwd_f32(const float *xyz, const float *center, const int64_t *idx, const float *Wq,
                                         const float *bq, const float *Wk, const float *bk, const float *Wv,
-                                        const float *bv, const uint8_t *argk, const float *grad_ctx, int B, int N,
-                                        int S, int K, int C, float *gWq, float *gbq, float *gWk, float *gbk,
-                                        float *gWv, float *gbv, void *stream)
+                                        const float *bv, int B, int N, int S, int K, int C, float *ctx, uint8_t *argk,
+                                        void *stream)
+{
+    return diffattn_xyz_fwd_any<float>(xyz, center, idx, Wq, bq, Wk, bk, Wv, bv, B, N, S, K, C, ctx, argk, stream);
+}
+
+extern "C" int mpa_diffattn_xyz_fwd_bf16(const float *xyz, const float *center, const int64_t *idx, const float *Wq,
+                                         const float *bq, const float *Wk, const float *bk, const float *Wv,
+                                         const float *bv, int B, int N, int S, int K, int C, mpa_bf16 *ctx,
+                                         uint8_t *argk, void *stream)
+{
+    return diffattn_xyz_fwd_any<bf16_t>(xyz, center, idx, Wq, bq, Wk, bk, Wv, bv, B, N, S, K, C,
+                                        reinterpret_cast<bf16_t *>(ctx), argk, stream);
+}
+
+template <typename TF>
+static int diffattn_xyz_bwd_any(const float *xyz, const float *center, const int64_t *idx, const float *Wq,
+                                const float *bq, const float *Wk, const float *bk, const float *Wv, const float *bv,
+                                const uint8_t *argk, const TF *grad_ctx, int B, int N, int S, int K, int C, float *gWq,
+                                float *gbq, float *gWk, float *gbk, float *gWv, float *gbv, void *stream)
 {
     MPA_CLEAR_ERROR();
     if (!xyz || !center || !idx || !Wq || !bq || !Wk || !bk || !Wv || !bv || !argk || !grad_ctx || !gWq || !gbq ||
@@ -773,11 +869,32 @@ extern "C" int mpa_diffattn_xyz_bwd_f32(const float *xyz, const float *center, c
     float alpha = 1.0f / sqrtf((float)C);
     hipStream_t st = (hipStream_t)stream;
     if (K == 8)
-        hipLaunchKernelGGL(diffattn_xyz_bwd_kernel<8>, grid, dim3(BWD_TPB), 0, st, xyz, center, idx, Wq, bq, Wk, bk, Wv,
+        hipLaunchKernelGGL((diffattn_xyz_bwd_kernel<8, TF>), grid, dim3(BWD_TPB), 0, st, xyz, center, idx, Wq, bq, Wk, bk, Wv,
                            bv, argk, grad_ctx, N, S, K, C, bx, alpha, np, gWq, gbq, gWk, gbk, gWv, gbv);
     else
-        hipLaunchKernelGGL(diffattn_xyz_bwd_kernel<0>, grid, dim3(BWD_TPB), 0, st, xyz, center, idx, Wq, bq, Wk, bk, Wv,
+        hipLaunchKernelGGL((diffattn_xyz_bwd_kernel<0, TF>), grid, dim3(BWD_TPB), 0, st, xyz, center, idx, Wq, bq, Wk, bk, Wv,
                            bv, argk, grad_ctx, N, S, K, C, bx, alpha, np, gWq, gbq, gWk, gbk, gWv, gbv);
     MPA_LAUNCH_CHECK();
     return MPA_OK;
+}
+
+extern "C" int mpa_diffattn_xyz_bwd_f32(const float *xyz, const float *center, const int64_t *idx, const float *Wq,
+                                        const float *bq, const float *Wk, const float *bk, const float *Wv,
+                                        const float *bv, const uint8_t *argk, const float *grad_ctx, int B, int N,
+                                        int S, int K, int C, float *gWq, float *gbq, float *gWk, float *gbk,
+                                        float *gWv, float *gbv, void *stream)
+{
+    return diffattn_xyz_bwd_any<float>(xyz, center, idx, Wq, bq, Wk, bk, Wv, bv, argk, grad_ctx, B, N, S, K, C, gWq, gbq,
+                                       gWk, gbk, gWv, gbv, stream);
+}
+
+extern "C" int mpa_diffattn_xyz_bwd_bf16(const float *xyz, const float *center, const int64_t *idx, const float *Wq,
+                                         const float *bq, const float *Wk, const float *bk, const float *Wv,
+                                         const float *bv, const uint8_t *argk, const mpa_bf16 *grad_ctx, int B, int N,
+                                         int S, int K, int C, float *gWq, float *gbq, float *gWk, float *gbk,
+                                         float *gWv, float *gbv, void *stream)
+{
+    return diffattn_xyz_bwd_any<bf16_t>(xyz, center, idx, Wq, bq, Wk, bk, Wv, bv, argk,
+                                        reinterpret_cast<const bf16_t *>(grad_ctx), B, N, S, K, C, gWq, gbq, gWk, gbk, gWv,
+                                        gbv, stream);
 }

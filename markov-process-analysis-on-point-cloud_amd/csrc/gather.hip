@@ -4,6 +4,7 @@
 // 1 KiB of contiguous row bytes per instruction; scatters use no-return float atomics on whole
 // rows (the shape that runs at the full atomic rate, MI355X guide "Global float atomics").
 #include "mpa_common.h"
+#include "mpa_bf16.h"
 #include "csr_build.h"
 #include <cstdlib>
 
@@ -28,7 +29,8 @@ __global__ void gather_fwd_kernel(const float *__restrict__ points, const int64_
 }
 
 // grad_points[b, idx[b,m], :] += grad_out[b,m,:]
-__global__ void gather_bwd_kernel(const float *__restrict__ grad_out, const int64_t *__restrict__ idx, int N, int M,
+template <typename T>
+__global__ void gather_bwd_kernel(const T *__restrict__ grad_out, const int64_t *__restrict__ idx, int N, int M,
                                   int C, long long total, float *__restrict__ grad_points)
 {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
@@ -37,7 +39,7 @@ __global__ void gather_bwd_kernel(const float *__restrict__ grad_out, const int6
         int c = (int)(i - row * C);
         int b = (int)(row / M);
         long long dst = (long long)b * N + mpa_clamp_idx(idx[row], N);
-        atomicAdd(grad_points + dst * C + c, grad_out[i]);
+        atomicAdd(grad_points + dst * C + c, mpa_ld1<T>(grad_out + i));
     }
 }
 
@@ -81,12 +83,12 @@ __global__ void upsample_divide_kernel(float *__restrict__ out, const float *__r
 // channels) sums the coarse rows that list n (once per coarse row: scatter_ semantics), counts those
 // whose channel 0 is non-zero and divides -- no float atomics (B*S*K*C of them ran at the chip's atomic
 // rate: 70 us per call in the part-seg decoder), no clearing pass, no separate divide.
-template <int V>
-__global__ __launch_bounds__(TPB) void upsample_gather_kernel(const float *__restrict__ points,
+template <int V, typename T>
+__global__ __launch_bounds__(TPB) void upsample_gather_kernel(const T *__restrict__ points,
                                                               const int64_t *__restrict__ knn,
                                                               const int *__restrict__ rowptr,
                                                               const int *__restrict__ entries, int S, int K, int Nf,
-                                                              int C, int lanes_per_row, float *__restrict__ out,
+                                                              int C, int lanes_per_row, T *__restrict__ out,
                                                               float *__restrict__ cnt)
 {
     const int rl = threadIdx.x / lanes_per_row, cl = threadIdx.x % lanes_per_row;
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(TPB) void upsample_gather_kernel(const float *__res
     const int beg = rp[n], end = rp[n + 1];
     const int *en = entries + (size_t)b * S * K;
     const int64_t *kb = knn + (size_t)b * S * K;
-    const float *pb = points + (size_t)b * S * C;
+    const T *pb = points + (size_t)b * S * C;
     for (int c = cl * V; c < C; c += lanes_per_row * V) {
         float acc[V];
 #pragma unroll
@@ -110,30 +112,31 @@ __global__ __launch_bounds__(TPB) void upsample_gather_kernel(const float *__res
             bool dup = false;                       // the same fine row listed earlier by this coarse row
             for (int j = 0; j < k; ++j) dup |= (mpa_clamp_idx(kb[(size_t)s * K + j], Nf) == n);
             if (dup) continue;
-            const float *row = pb + (size_t)s * C;
+            const T *row = pb + (size_t)s * C;
             if constexpr (V == 4) {
-                const float4 v = *reinterpret_cast<const float4 *>(row + c);
+                const float4 v = mpa_ld4<T>(row + c);
                 acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
             } else {
-                acc[0] += row[c];
+                acc[0] += mpa_ld1<T>(row + c);
             }
-            div += row[0] != 0.0f ? 1.f : 0.f;
+            div += mpa_ld1<T>(row) != 0.0f ? 1.f : 0.f;
         }
         if (c == 0) cnt[(size_t)b * Nf + n] = div;
         const float d = div == 0.f ? 1.f : div;
-        float *o = out + ((size_t)b * Nf + n) * C + c;
+        T *o = out + ((size_t)b * Nf + n) * C + c;
         if constexpr (V == 4) {
-            *reinterpret_cast<float4 *>(o) = make_float4(acc[0] / d, acc[1] / d, acc[2] / d, acc[3] / d);
+            mpa_st4<T>(o, make_float4(acc[0] / d, acc[1] / d, acc[2] / d, acc[3] / d));
         } else {
-            o[0] = acc[0] / d;
+            mpa_st1<T>(o, acc[0] / d);
         }
     }
 }
 
 // grad_points[b,s,:] = sum over distinct n in knn[b,s,:] of grad_out[b,n,:] / max(cnt[b,n],1)
-__global__ void upsample_bwd_kernel(const float *__restrict__ grad_out, const int64_t *__restrict__ knn,
+template <typename T>
+__global__ void upsample_bwd_kernel(const T *__restrict__ grad_out, const int64_t *__restrict__ knn,
                                     const float *__restrict__ cnt, int S, int K, int Nf, int C, long long total,
-                                    float *__restrict__ grad_points)
+                                    T *__restrict__ grad_points)
 {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
@@ -150,9 +153,9 @@ __global__ void upsample_bwd_kernel(const float *__restrict__ grad_out, const in
             long long src = (long long)b * Nf + n;
             float d = cnt[src];
             d = d == 0.0f ? 1.0f : d;
-            acc += grad_out[src * C + c] / d;
+            acc += mpa_ld1<T>(grad_out + src * C + c) / d;
         }
-        grad_points[i] = acc;
+        mpa_st1<T>(grad_points + i, acc);
     }
 }
 
@@ -246,8 +249,43 @@ extern "C" int mpa_gather_bwd_f32(const float *grad_out, const int64_t *idx, int
     MPA_CLEAR_ERROR();
     if (!grad_out || !idx || !grad_points || B <= 0 || N <= 0 || M <= 0 || C <= 0) return MPA_EINVAL;
     long long total = (long long)B * M * C;
-    hipLaunchKernelGGL(gather_bwd_kernel, dim3(grid_for(total)), dim3(TPB), 0, (hipStream_t)stream, grad_out, idx, N,
+    hipLaunchKernelGGL(gather_bwd_kernel<float>, dim3(grid_for(total)), dim3(TPB), 0, (hipStream_t)stream, grad_out, idx, N,
                        M, C, total, grad_points);
+    MPA_LAUNCH_CHECK();
+    return MPA_OK;
+}
+
+extern "C" int mpa_gather_fwd_bf16(const mpa_bf16 *points, const int64_t *idx, int B, int N, int M, int C, mpa_bf16 *out,
+                                   void *stream)
+{
+    MPA_CLEAR_ERROR();
+    if (!points || !idx || !out || B <= 0 || N <= 0 || M <= 0 || C <= 0) return MPA_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    // a row move: bf16 rows are copied as 16-B / 4-B pieces of their bytes
+    const float *pf = reinterpret_cast<const float *>(points);
+    float *of = reinterpret_cast<float *>(out);
+    const bool al16 = (((uintptr_t)points | (uintptr_t)out) & 15) == 0;
+    if ((C & 7) == 0 && al16) {
+        long long total = (long long)B * M * (C / 8);
+        hipLaunchKernelGGL(gather_fwd_kernel<float4>, dim3(grid_for(total)), dim3(TPB), 0, st, pf, idx, N, M, C / 8, total, of);
+    } else if ((C & 1) == 0 && (((uintptr_t)points | (uintptr_t)out) & 3) == 0) {
+        long long total = (long long)B * M * (C / 2);
+        hipLaunchKernelGGL(gather_fwd_kernel<float>, dim3(grid_for(total)), dim3(TPB), 0, st, pf, idx, N, M, C / 2, total, of);
+    } else {
+        return MPA_EUNSUPPORTED;
+    }
+    MPA_LAUNCH_CHECK();
+    return MPA_OK;
+}
+
+extern "C" int mpa_gather_bwd_bf16(const mpa_bf16 *grad_out, const int64_t *idx, int B, int N, int M, int C,
+                                   float *grad_points, void *stream)
+{
+    MPA_CLEAR_ERROR();
+    if (!grad_out || !idx || !grad_points || B <= 0 || N <= 0 || M <= 0 || C <= 0) return MPA_EINVAL;
+    long long total = (long long)B * M * C;
+    hipLaunchKernelGGL(gather_bwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(TPB), 0, (hipStream_t)stream,
+                       reinterpret_cast<const bf16_t *>(grad_out), idx, N, M, C, total, grad_points);
     MPA_LAUNCH_CHECK();
     return MPA_OK;
 }
@@ -277,10 +315,10 @@ extern "C" int mpa_upsample_mean_fwd_f32(const float *points, const int64_t *knn
         while (lanes < per && lanes < TPB) lanes <<= 1;
         const dim3 grid(mpa_ceil_div(Nf, TPB / lanes), B);
         if (v4)
-            hipLaunchKernelGGL(upsample_gather_kernel<4>, grid, dim3(TPB), 0, st, points, knn_idx, rowptr, entries, S, K,
+            hipLaunchKernelGGL((upsample_gather_kernel<4, float>), grid, dim3(TPB), 0, st, points, knn_idx, rowptr, entries, S, K,
                                Nf, C, lanes, out, cnt);
         else
-            hipLaunchKernelGGL(upsample_gather_kernel<1>, grid, dim3(TPB), 0, st, points, knn_idx, rowptr, entries, S, K,
+            hipLaunchKernelGGL((upsample_gather_kernel<1, float>), grid, dim3(TPB), 0, st, points, knn_idx, rowptr, entries, S, K,
                                Nf, C, lanes, out, cnt);
         MPA_LAUNCH_CHECK();
         return MPA_OK;
@@ -303,8 +341,52 @@ extern "C" int mpa_upsample_mean_bwd_f32(const float *grad_out, const int64_t *k
     if (!grad_out || !knn_idx || !cnt || !grad_points || B <= 0 || S <= 0 || K <= 0 || Nf <= 0 || C <= 0)
         return MPA_EINVAL;
     long long total = (long long)B * S * C;
-    hipLaunchKernelGGL(upsample_bwd_kernel, dim3(grid_for(total)), dim3(TPB), 0, (hipStream_t)stream, grad_out,
+    hipLaunchKernelGGL(upsample_bwd_kernel<float>, dim3(grid_for(total)), dim3(TPB), 0, (hipStream_t)stream, grad_out,
                        knn_idx, cnt, S, K, Nf, C, total, grad_points);
+    MPA_LAUNCH_CHECK();
+    return MPA_OK;
+}
+
+// bf16 rows: the inverted-table gather only (the workspace is required: no atomic fallback on bf16)
+extern "C" int mpa_upsample_mean_fwd_bf16(const mpa_bf16 *points, const int64_t *knn_idx, int B, int S, int K, int Nf,
+                                          int C, mpa_bf16 *out, float *cnt, void *workspace, size_t workspace_bytes,
+                                          void *stream)
+{
+    MPA_CLEAR_ERROR();
+    if (!points || !knn_idx || !out || !cnt || B <= 0 || S <= 0 || K <= 0 || Nf <= 0 || C <= 0) return MPA_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t need = mpa_upsample_workspace_bytes(B, S, K, Nf);
+    if (!workspace || !need || workspace_bytes < need || ((uintptr_t)workspace & 15) != 0) return MPA_EUNSUPPORTED;
+    int *rowptr = reinterpret_cast<int *>(workspace);
+    int *entries = reinterpret_cast<int *>((char *)workspace + (((size_t)B * (Nf + 1) * 4 + 255) & ~(size_t)255));
+    launch_csr_build(knn_idx, B, Nf, S * K, rowptr, entries, st);
+    const bf16_t *pb = reinterpret_cast<const bf16_t *>(points);
+    bf16_t *ob = reinterpret_cast<bf16_t *>(out);
+    const bool v4 = (C & 3) == 0 && ((((uintptr_t)points | (uintptr_t)out)) & 7) == 0;
+    const int per = v4 ? C / 4 : C;
+    int lanes = 1;
+    while (lanes < per && lanes < TPB) lanes <<= 1;
+    const dim3 grid(mpa_ceil_div(Nf, TPB / lanes), B);
+    if (v4)
+        hipLaunchKernelGGL((upsample_gather_kernel<4, bf16_t>), grid, dim3(TPB), 0, st, pb, knn_idx, rowptr, entries, S, K,
+                           Nf, C, lanes, ob, cnt);
+    else
+        hipLaunchKernelGGL((upsample_gather_kernel<1, bf16_t>), grid, dim3(TPB), 0, st, pb, knn_idx, rowptr, entries, S, K,
+                           Nf, C, lanes, ob, cnt);
+    MPA_LAUNCH_CHECK();
+    return MPA_OK;
+}
+
+extern "C" int mpa_upsample_mean_bwd_bf16(const mpa_bf16 *grad_out, const int64_t *knn_idx, const float *cnt, int B,
+                                          int S, int K, int Nf, int C, mpa_bf16 *grad_points, void *stream)
+{
+    MPA_CLEAR_ERROR();
+    if (!grad_out || !knn_idx || !cnt || !grad_points || B <= 0 || S <= 0 || K <= 0 || Nf <= 0 || C <= 0)
+        return MPA_EINVAL;
+    long long total = (long long)B * S * C;
+    hipLaunchKernelGGL(upsample_bwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(TPB), 0, (hipStream_t)stream,
+                       reinterpret_cast<const bf16_t *>(grad_out), knn_idx, cnt, S, K, Nf, C, total,
+                       reinterpret_cast<bf16_t *>(grad_points));
     MPA_LAUNCH_CHECK();
     return MPA_OK;
 }

@@ -14,6 +14,8 @@
 // Most layers here are K,N in {64,128}: arithmetic intensity ~16 FLOP/B against a machine
 // balance of ~25, i.e. HBM-bound; the wide layers (512..2048) are MFMA-bound.
 #include "mpa_common.h"
+#include "mpa_bf16.h"
+#include "splitk_reduce.h"
 #include <cstdlib>
 #include <type_traits>
 
@@ -452,7 +454,6 @@ struct GroupedProblem {
     float *out, *a_col_sum, *slab;       // slab: split-K partial tiles [splits][M*N] (or nullptr: direct)
     int lda, ldb, M, N, K, kchunk, splits, tiles, vec, stream;
 };
-constexpr int GROUP_MAX = 40;
 struct GroupedArgs {
     int count;
     int block_start[GROUP_MAX + 1];      // prefix sum of tiles*splits
@@ -478,36 +479,6 @@ __global__ __launch_bounds__(NT, 2) void gemm_tn_grouped_kernel(const GroupedArg
     else
         gemm_body<true, false>(tile, z, q.A, q.lda, q.B, q.ldb, nullptr, q.out, q.N, q.M, q.N, q.K, q.kchunk, 0, vecA,
                                vecB, nullptr, nullptr, q.a_col_sum, q.stream);
-}
-
-// out_p[M*N] += sum_z slab_p[z][M*N] for all problems of a group (out_p cleared by the z = 0 tiles above)
-struct GroupedReduceArgs {
-    int count;
-    int block_start[GROUP_MAX + 1];      // prefix sum of ceil(mn/256)*gy
-    struct { const float *slab; float *out; int mn, splits, gx, gy; } p[GROUP_MAX];
-};
-
-__global__ void splitk_reduce_grouped_kernel(const GroupedReduceArgs args)
-{
-    int b = blockIdx.x, i = 0;
-    while (i + 1 < args.count && b >= args.block_start[i + 1]) ++i;
-    const auto &q = args.p[i];
-    const int local = b - args.block_start[i];
-    const int bx = local % q.gx, by = local / q.gx;
-    const long long e = bx * 256LL + threadIdx.x;
-    if (e >= q.mn) return;
-    const int zper = (q.splits + q.gy - 1) / q.gy;
-    const int z0 = by * zper, z1 = min(q.splits, z0 + zper);
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int z = z0;
-    for (; z + 3 < z1; z += 4) {
-        a0 += q.slab[(size_t)z * q.mn + e];
-        a1 += q.slab[(size_t)(z + 1) * q.mn + e];
-        a2 += q.slab[(size_t)(z + 2) * q.mn + e];
-        a3 += q.slab[(size_t)(z + 3) * q.mn + e];
-    }
-    for (; z < z1; ++z) a0 += q.slab[(size_t)z * q.mn + e];
-    if (z0 < z1) atomicAdd(q.out + e, (a0 + a1) + (a2 + a3));
 }
 
 // ---- short-K products (K = 64 or 128, whole tiles): the layers of the fine point-set states,
@@ -782,11 +753,12 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float *__restri
 
 // y = lrelu((x - mean[c]) * invstd[c] * gamma[c] + beta[c]); every workgroup stages the
 // per-channel scale/shift in LDS, then streams its share of the rows with float4 accesses.
-__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float *__restrict__ x, const float *__restrict__ save,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T *__restrict__ x, const float *__restrict__ save,
                                                          const float *__restrict__ gamma,
                                                          const float *__restrict__ beta,
-                                                         const float *__restrict__ residual, float slope, int M,
-                                                         int C, float *__restrict__ y)
+                                                         const T *__restrict__ residual, float slope, int M,
+                                                         int C, T *__restrict__ y)
 {
     extern __shared__ float ss[];          // scale[C], shift[C]
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -801,7 +773,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float *__restrict
         for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4;
              i += (long long)gridDim.x * blockDim.x) {
             const int c = (int)(i % c4n) * 4;
-            const float4 v = reinterpret_cast<const float4 *>(x)[i];
+            const float4 v = mpa_ld4<T>(x + 4 * i);
             const float4 sc = *reinterpret_cast<const float4 *>(ss + c);
             const float4 sh = *reinterpret_cast<const float4 *>(ss + C + c);
             float4 o;
@@ -810,19 +782,19 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float *__restrict
             o.x = o.x > 0.f ? o.x : o.x * slope; o.y = o.y > 0.f ? o.y : o.y * slope;
             o.z = o.z > 0.f ? o.z : o.z * slope; o.w = o.w > 0.f ? o.w : o.w * slope;
             if (residual != nullptr) {
-                const float4 r = reinterpret_cast<const float4 *>(residual)[i];
+                const float4 r = mpa_ld4<T>(residual + 4 * i);
                 o.x = r.x + o.x; o.y = r.y + o.y; o.z = r.z + o.z; o.w = r.w + o.w;
             }
-            reinterpret_cast<float4 *>(y)[i] = o;
+            mpa_st4<T>(y + 4 * i, o);
         }
     } else {
         const long long total = (long long)M * C;
         for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
              i += (long long)gridDim.x * blockDim.x) {
             const int c = (int)(i % C);
-            float t = fmaf(x[i], ss[c], ss[C + c]);
+            float t = fmaf(mpa_ld1<T>(x + i), ss[c], ss[C + c]);
             t = t > 0.f ? t : t * slope;
-            y[i] = residual != nullptr ? residual[i] + t : t;
+            mpa_st1<T>(y + i, residual != nullptr ? mpa_ld1<T>(residual + i) + t : t);
         }
     }
 }
@@ -892,17 +864,18 @@ __device__ __forceinline__ void slab_reduce2(int M, int C, int cpb, int rows_per
 }
 
 // Backward pass 1: g = grad_y * lrelu'(bn(x)); per channel sum(g) and sum(g*xhat).
+template <typename T>
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(
-    const float *__restrict__ x, const float *__restrict__ gy, const float *__restrict__ mean,
+    const T *__restrict__ x, const T *__restrict__ gy, const float *__restrict__ mean,
     const float *__restrict__ invstd, const float *__restrict__ gamma, const float *__restrict__ beta, float slope,
     int M, int C, int ldg, int cpb, int rows_per_block, float *__restrict__ partial, int replicas)
 {
     float *sum_g = partial + (size_t)(blockIdx.x % replicas) * 2 * C;
     float *sum_gx = sum_g + C;
     slab_reduce2(M, C, cpb, rows_per_block, sum_g, sum_gx, [&](int r, int c, float &sg, float &sgx) {
-        const float xh = (x[(size_t)r * C + c] - mean[c]) * invstd[c];
+        const float xh = (mpa_ld1<T>(x + (size_t)r * C + c) - mean[c]) * invstd[c];
         const float t = xh * gamma[c] + beta[c];
-        float g = gy[(size_t)r * ldg + c];
+        float g = mpa_ld1<T>(gy + (size_t)r * ldg + c);
         g = t > 0.f ? g : g * slope;
         sg += g;
         sgx = fmaf(g, xh, sgx);
@@ -912,8 +885,9 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(
 // float4 form (C % 4 == 0): a lane owns 4 adjacent channels, 256 lanes = RY rows x C/4 lanes, two
 // rows (4 x 16-B loads) in flight per lane; RY partials combined through LDS, one atomic per
 // (workgroup, channel).
+template <typename T>
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce4_kernel(
-    const float *__restrict__ x, const float *__restrict__ gy, const float *__restrict__ mean,
+    const T *__restrict__ x, const T *__restrict__ gy, const float *__restrict__ mean,
     const float *__restrict__ invstd, const float *__restrict__ gamma, const float *__restrict__ beta, float slope,
     int M, int C, int ldg, int lanes_per_row, int rows_per_block, float *__restrict__ partial, int replicas)
 {
@@ -939,16 +913,15 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce4_kernel(
         };
         int r = r0 + ry;
         for (; r + RY < r1; r += 2 * RY) {
-            const float4 x0 = *reinterpret_cast<const float4 *>(x + (size_t)r * C + c);
-            const float4 g0 = *reinterpret_cast<const float4 *>(gy + (size_t)r * ldg + c);
-            const float4 x1 = *reinterpret_cast<const float4 *>(x + (size_t)(r + RY) * C + c);
-            const float4 g1 = *reinterpret_cast<const float4 *>(gy + (size_t)(r + RY) * ldg + c);
+            const float4 x0 = mpa_ld4<T>(x + (size_t)r * C + c);
+            const float4 g0 = mpa_ld4<T>(gy + (size_t)r * ldg + c);
+            const float4 x1 = mpa_ld4<T>(x + (size_t)(r + RY) * C + c);
+            const float4 g1 = mpa_ld4<T>(gy + (size_t)(r + RY) * ldg + c);
             acc1(x0, g0);
             acc1(x1, g1);
         }
         for (; r < r1; r += RY)
-            acc1(*reinterpret_cast<const float4 *>(x + (size_t)r * C + c),
-                 *reinterpret_cast<const float4 *>(gy + (size_t)r * ldg + c));
+            acc1(mpa_ld4<T>(x + (size_t)r * C + c), mpa_ld4<T>(gy + (size_t)r * ldg + c));
     }
     red[0][tid] = sg;
     red[1][tid] = sx;
@@ -969,11 +942,12 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce4_kernel(
 
 // Backward pass 2: grad_x = gamma*invstd*(g - sum_g/M - xhat*sum_gx/M)   (batch statistics)
 //                  grad_x = gamma*invstd*g                                (running statistics)
+template <typename T>
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
-    const float *__restrict__ x, const float *__restrict__ gy, const float *__restrict__ mean,
+    const T *__restrict__ x, const T *__restrict__ gy, const float *__restrict__ mean,
     const float *__restrict__ invstd, const float *__restrict__ gamma, const float *__restrict__ beta,
     const float *__restrict__ partial, int replicas, float slope, int use_batch_stats, int M, int C, int ldg,
-    long long total, float *__restrict__ gx, float *__restrict__ dgamma, float *__restrict__ dbeta)
+    long long total, T *__restrict__ gx, float *__restrict__ dgamma, float *__restrict__ dbeta)
 {
     // per-channel constants in LDS: k1 = gamma*invstd, then grad_x = k1*(g - a - xhat*b) with
     // a = sum_g/M, b = sum_gxhat/M (zero in eval mode); totals of the replicas also go out as
@@ -1006,7 +980,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
         }
     }
     __syncthreads();
-    const bool v4 = ((C & 3) == 0) && ((ldg & 3) == 0) && (((((uintptr_t)x | (uintptr_t)gy | (uintptr_t)gx)) & 15) == 0);
+    const bool v4 = ((C & 3) == 0) && ((ldg & 3) == 0) &&
+                    (((((uintptr_t)x | (uintptr_t)gy | (uintptr_t)gx)) & mpa_vec4_align<T>::mask) == 0);
     if (v4) {
         const long long total4 = total / 4;
         const int c4n = C / 4;
@@ -1014,8 +989,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
              i += (long long)gridDim.x * blockDim.x) {
             const long long row = i / c4n;
             const int c = (int)(i - row * c4n) * 4;
-            const float4 xv = reinterpret_cast<const float4 *>(x)[i];
-            const float4 gv = *reinterpret_cast<const float4 *>(gy + row * ldg + c);
+            const float4 xv = mpa_ld4<T>(x + 4 * i);
+            const float4 gv = mpa_ld4<T>(gy + row * ldg + c);
             const float xin[4] = {xv.x, xv.y, xv.z, xv.w}, gin[4] = {gv.x, gv.y, gv.z, gv.w};
             float o[4];
 #pragma unroll
@@ -1026,7 +1001,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
                 const float g = t > 0.f ? gin[j] : gin[j] * slope;
                 o[j] = ga * is * (g - cs[4 * C + c + j] - xh * cs[5 * C + c + j]);
             }
-            reinterpret_cast<float4 *>(gx)[i] = make_float4(o[0], o[1], o[2], o[3]);
+            mpa_st4<T>(gx + 4 * i, make_float4(o[0], o[1], o[2], o[3]));
         }
         return;
     }
@@ -1035,11 +1010,11 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
         const long long row = i / C;
         const int c = (int)(i - row * C);
         const float is = cs[C + c], ga = cs[2 * C + c];
-        const float xh = (x[i] - cs[c]) * is;
+        const float xh = (mpa_ld1<T>(x + i) - cs[c]) * is;
         const float t = xh * ga + cs[3 * C + c];
-        const float g0 = gy[row * ldg + c];
+        const float g0 = mpa_ld1<T>(gy + row * ldg + c);
         const float g = t > 0.f ? g0 : g0 * slope;
-        gx[i] = ga * is * (g - cs[4 * C + c] - xh * cs[5 * C + c]);
+        mpa_st1<T>(gx + i, ga * is * (g - cs[4 * C + c] - xh * cs[5 * C + c]));
     }
 }
 
@@ -1303,32 +1278,49 @@ extern "C" int mpa_col_sum_f32(const float *x, int M, int C, int ld, float *out,
     return MPA_OK;
 }
 
-extern "C" int mpa_bn_act_fwd_f32(const float *x, const float *save_mean_invstd, const float *gamma,
-                                  const float *beta, const float *residual, float slope, int M, int C, float *y,
-                                  void *stream)
+template <typename T>
+static int bn_act_fwd_any(const T *x, const float *save_mean_invstd, const float *gamma, const float *beta,
+                          const T *residual, float slope, int M, int C, T *y, void *stream)
 {
     MPA_CLEAR_ERROR();
     if (!x || !save_mean_invstd || !gamma || !beta || !y || M <= 0 || C <= 0) return MPA_EINVAL;
     if (C > 8192) return MPA_EUNSUPPORTED;
-    const bool al = (((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual) & 15) == 0;
+    const bool al = (((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual) & mpa_vec4_align<T>::mask) == 0;
     if ((C & 3) == 0 && !al) return MPA_EUNSUPPORTED;
     long long total = (long long)M * C;
-    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(ew_grid(total / 4 + 1)), dim3(EW_TPB), 2 * C * sizeof(float),
+    hipLaunchKernelGGL(bn_act_fwd_kernel<T>, dim3(ew_grid(total / 4 + 1)), dim3(EW_TPB), 2 * C * sizeof(float),
                        (hipStream_t)stream, x, save_mean_invstd, gamma, beta, residual, slope, M, C, y);
     MPA_LAUNCH_CHECK();
     return MPA_OK;
 }
 
-extern "C" int mpa_bn_act_bwd_reduce_f32(const float *x, const float *grad_y, const float *mean, const float *invstd,
-                                         const float *gamma, const float *beta, float slope, int M, int C,
-                                         int ldg, float *partial, int replicas, void *stream)
+extern "C" int mpa_bn_act_fwd_f32(const float *x, const float *save_mean_invstd, const float *gamma,
+                                  const float *beta, const float *residual, float slope, int M, int C, float *y,
+                                  void *stream)
+{
+    return bn_act_fwd_any<float>(x, save_mean_invstd, gamma, beta, residual, slope, M, C, y, stream);
+}
+
+extern "C" int mpa_bn_act_fwd_bf16(const mpa_bf16 *x, const float *save_mean_invstd, const float *gamma,
+                                   const float *beta, const mpa_bf16 *residual, float slope, int M, int C, mpa_bf16 *y,
+                                   void *stream)
+{
+    return bn_act_fwd_any<bf16_t>(reinterpret_cast<const bf16_t *>(x), save_mean_invstd, gamma, beta,
+                                  reinterpret_cast<const bf16_t *>(residual), slope, M, C,
+                                  reinterpret_cast<bf16_t *>(y), stream);
+}
+
+template <typename T>
+static int bn_act_bwd_reduce_any(const T *x, const T *grad_y, const float *mean, const float *invstd,
+                                 const float *gamma, const float *beta, float slope, int M, int C, int ldg,
+                                 float *partial, int replicas, void *stream)
 {
     MPA_CLEAR_ERROR();
     if (!x || !grad_y || !mean || !invstd || !gamma || !beta || !partial || replicas <= 0 || M <= 0 || C <= 0 ||
         ldg < C)
         return MPA_EINVAL;
-    const bool al = ((((uintptr_t)x | (uintptr_t)grad_y | (uintptr_t)mean | (uintptr_t)invstd | (uintptr_t)gamma |
-                       (uintptr_t)beta)) & 15) == 0;
+    const bool al = ((((uintptr_t)x | (uintptr_t)grad_y) & mpa_vec4_align<T>::mask) == 0) &&
+                    (((((uintptr_t)mean | (uintptr_t)invstd | (uintptr_t)gamma | (uintptr_t)beta)) & 15) == 0);
     if ((C & 3) == 0 && (ldg & 3) == 0 && al) {
         int lanes = C / 4;                                   // lanes per row: a divisor of 256
         lanes = lanes >= 256 ? 256 : (lanes > 128 ? 256 : (lanes > 64 ? 128 : (lanes > 32 ? 64 : (lanes > 16 ? 32 : 16))));
@@ -1337,16 +1329,50 @@ extern "C" int mpa_bn_act_bwd_reduce_f32(const float *x, const float *grad_y, co
         int want = 1024 / gy_;
         int rpb = mpa_ceil_div(M, want < 1 ? 1 : want);
         if (rpb < 2 * ry) rpb = 2 * ry;
-        hipLaunchKernelGGL(bn_act_bwd_reduce4_kernel, dim3(mpa_ceil_div(M, rpb), gy_), dim3(256), 0,
+        hipLaunchKernelGGL(bn_act_bwd_reduce4_kernel<T>, dim3(mpa_ceil_div(M, rpb), gy_), dim3(256), 0,
                            (hipStream_t)stream, x, grad_y, mean, invstd, gamma, beta, slope, M, C, ldg, lanes, rpb, partial,
                            replicas);
     } else {
         dim3 grid;
         int cpb, rpb;
         slab_grid(M, C, grid, cpb, rpb);
-        hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, grad_y, mean, invstd,
+        hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, x, grad_y, mean, invstd,
                            gamma, beta, slope, M, C, ldg, cpb, rpb, partial, replicas);
     }
+    MPA_LAUNCH_CHECK();
+    return MPA_OK;
+}
+
+extern "C" int mpa_bn_act_bwd_reduce_f32(const float *x, const float *grad_y, const float *mean, const float *invstd,
+                                         const float *gamma, const float *beta, float slope, int M, int C,
+                                         int ldg, float *partial, int replicas, void *stream)
+{
+    return bn_act_bwd_reduce_any<float>(x, grad_y, mean, invstd, gamma, beta, slope, M, C, ldg, partial, replicas, stream);
+}
+
+extern "C" int mpa_bn_act_bwd_reduce_bf16(const mpa_bf16 *x, const mpa_bf16 *grad_y, const float *mean,
+                                          const float *invstd, const float *gamma, const float *beta, float slope, int M,
+                                          int C, int ldg, float *partial, int replicas, void *stream)
+{
+    return bn_act_bwd_reduce_any<bf16_t>(reinterpret_cast<const bf16_t *>(x), reinterpret_cast<const bf16_t *>(grad_y), mean,
+                                         invstd, gamma, beta, slope, M, C, ldg, partial, replicas, stream);
+}
+
+template <typename T>
+static int bn_act_bwd_apply_any(const T *x, const T *grad_y, const float *mean, const float *invstd,
+                                const float *gamma, const float *beta, const float *partial, int replicas, float slope,
+                                int use_batch_stats, int M, int C, int ldg, T *grad_x, float *dgamma, float *dbeta,
+                                void *stream)
+{
+    MPA_CLEAR_ERROR();
+    if (!x || !grad_y || !mean || !invstd || !gamma || !beta || !grad_x || !partial || replicas <= 0 || M <= 0 ||
+        C <= 0 || ldg < C)
+        return MPA_EINVAL;
+    if (C > 8192) return MPA_EUNSUPPORTED;
+    long long total = (long long)M * C;
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel<T>, dim3(ew_grid(total / 4 + 1)), dim3(EW_TPB), 6 * C * sizeof(float),
+                       (hipStream_t)stream, x, grad_y, mean, invstd, gamma, beta, partial, replicas, slope,
+                       use_batch_stats, M, C, ldg, total, grad_x, dgamma, dbeta);
     MPA_LAUNCH_CHECK();
     return MPA_OK;
 }
@@ -1356,15 +1382,16 @@ extern "C" int mpa_bn_act_bwd_apply_f32(const float *x, const float *grad_y, con
                                         float slope, int use_batch_stats, int M, int C, int ldg, float *grad_x,
                                         float *dgamma, float *dbeta, void *stream)
 {
-    MPA_CLEAR_ERROR();
-    if (!x || !grad_y || !mean || !invstd || !gamma || !beta || !grad_x || !partial || replicas <= 0 || M <= 0 ||
-        C <= 0 || ldg < C)
-        return MPA_EINVAL;
-    if (C > 8192) return MPA_EUNSUPPORTED;
-    long long total = (long long)M * C;
-    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ew_grid(total / 4 + 1)), dim3(EW_TPB), 6 * C * sizeof(float),
-                       (hipStream_t)stream, x, grad_y, mean, invstd, gamma, beta, partial, replicas, slope,
-                       use_batch_stats, M, C, ldg, total, grad_x, dgamma, dbeta);
-    MPA_LAUNCH_CHECK();
-    return MPA_OK;
+    return bn_act_bwd_apply_any<float>(x, grad_y, mean, invstd, gamma, beta, partial, replicas, slope, use_batch_stats, M,
+                                       C, ldg, grad_x, dgamma, dbeta, stream);
+}
+
+extern "C" int mpa_bn_act_bwd_apply_bf16(const mpa_bf16 *x, const mpa_bf16 *grad_y, const float *mean,
+                                         const float *invstd, const float *gamma, const float *beta, const float *partial,
+                                         int replicas, float slope, int use_batch_stats, int M, int C, int ldg,
+                                         mpa_bf16 *grad_x, float *dgamma, float *dbeta, void *stream)
+{
+    return bn_act_bwd_apply_any<bf16_t>(reinterpret_cast<const bf16_t *>(x), reinterpret_cast<const bf16_t *>(grad_y), mean,
+                                        invstd, gamma, beta, partial, replicas, slope, use_batch_stats, M, C, ldg,
+                                        reinterpret_cast<bf16_t *>(grad_x), dgamma, dbeta, stream);
 }

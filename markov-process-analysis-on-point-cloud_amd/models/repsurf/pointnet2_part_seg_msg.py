@@ -1,6 +1,7 @@
 """Part-segmentation wiring -- drop-in for the reference's
 models/repsurf/pointnet2_part_seg_msg.py:33-180 (get_model, get_loss).  State-dict keys equal
 the reference's."""
+import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
@@ -27,7 +28,8 @@ class get_model(nn.Module):
         _, final_points = self.keepHigh(xyz, normal=xyz, label=cls_label)
         x = self.drop1(self.conv8(final_points))
         x = self.conv10(self.conv9(x))
-        return ops.linear(x, self.conv11.weight, self.conv11.bias), xyz
+        # logits leave the feature stream in fp32 (on bf16 features the product's fp32 results are stored unrounded)
+        return ops.linear(x, self.conv11.weight, self.conv11.bias, out_dtype=torch.float32), xyz
 
 
 class get_loss(nn.Module):

@@ -1,6 +1,7 @@
 """Classification wiring -- drop-in for the reference's models/repsurf/repsurf_ssg_umb.py:35-70
 (class Model): KeepHighResolutionModule + a three-layer FC head, log-softmax output.
 State-dict keys equal the reference's."""
+import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
@@ -29,7 +30,7 @@ class Model(nn.Module):
         x = self.keepHigh(center, normal)
         x = self.drop1(ops.linear_bn_act(x, self.fc1.weight, self.fc1.bias, self.bn1, 0.2))
         x = self.drop2(ops.linear_bn_act(x, self.fc2.weight, self.fc2.bias, self.bn2, 0.2))
-        return F.log_softmax(ops.linear(x, self.fc3.weight, self.fc3.bias), -1)
+        return F.log_softmax(ops.linear(x, self.fc3.weight, self.fc3.bias, out_dtype=torch.float32), -1)
 
 
 class SmoothClsLoss(nn.Module):

@@ -418,7 +418,7 @@ class KeepHighResolutionModulePartSeg(nn.Module):
 
         glob = torch.cat([_max_over_points(t) for t in (d0, d1, d2, d3, d4)], dim=2)
         glob = glob.expand(-1, N, -1)
-        lab = self.conv7(label).expand(-1, N, -1)
+        lab = self.conv7(label.to(d0.dtype)).expand(-1, N, -1)          # (the one-hot joins the feature stream's dtype)
         final = torch.cat((self.conv5(d0), glob, lab), 2)
         return x0, final
 

@@ -12,7 +12,7 @@ import os
 
 import torch
 
-from ._lib import lib, check, GemmTnProblem
+from ._lib import lib, check, GemmTnProblem, GemmTnProblemBf16
 
 _vp = ctypes.c_void_p
 
@@ -98,6 +98,52 @@ def _f32(t):
 
 def _i64(t):
     return t.to(torch.int64).contiguous()
+
+
+# ---- feature precision -------------------------------------------------------------------------
+# Features (activations and their gradients) are stored fp32 (default: the reference's precision, the
+# parity path) or bf16 (BASELINE configs 3 and 5: "features / GEMM operands bf16, fp32 accumulate;
+# coordinates, distances, indices, BatchNorm statistics and optimizer state fp32").  Every op
+# dispatches on the dtype of the feature tensor it is handed; FEATURE_DTYPE only decides what the ops
+# that CREATE features from fp32 inputs emit (the xyz branch of LocalTrans, on raw coordinates).
+FEATURE_DTYPE = torch.float32
+_FEATURE_DTYPES = (torch.float32, torch.bfloat16)
+
+
+def set_feature_dtype(dtype):
+    """torch.float32 (reference precision) or torch.bfloat16 (bf16 feature path).  Returns the old value."""
+    global FEATURE_DTYPE
+    if dtype not in _FEATURE_DTYPES:
+        raise TypeError("feature dtype must be float32 or bfloat16, got %s" % dtype)
+    old, FEATURE_DTYPE = FEATURE_DTYPE, dtype
+    return old
+
+
+class feature_dtype:
+    """with ops.feature_dtype(torch.bfloat16): ...   (context-manager form of set_feature_dtype)"""
+
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+    def __enter__(self):
+        self.old = set_feature_dtype(self.dtype)
+        return self
+
+    def __exit__(self, *a):
+        set_feature_dtype(self.old)
+        return False
+
+
+def _feat(t):
+    """a feature tensor: fp32 or bf16, made contiguous"""
+    if t.dtype not in _FEATURE_DTYPES:
+        raise TypeError("expected a float32 or bfloat16 feature tensor, got %s" % t.dtype)
+    return t.contiguous()
+
+
+def _sfx(t):
+    """entry-point suffix for a feature tensor's storage type"""
+    return "bf16" if t.dtype == torch.bfloat16 else "f32"
 
 
 # ------------------------------------------------------------------------------- sampling
@@ -209,7 +255,9 @@ def knn_point(nsample, xyz, new_xyz):
     """reference: modules/pointnet2_utils.py:211-222.  Returns (dist [B,S,k], idx int64 [B,S,k]),
     ascending.  Indices are not differentiable; dist carries no gradient (the models never use it)."""
     _dev(xyz, new_xyz)
-    base, query = _f32(xyz.detach()), _f32(new_xyz.detach())
+    # bf16 features: the search runs on their exact fp32 values (distances and indices are always fp32 /
+    # int64 work: the result is the reference's arithmetic applied to the rounded features)
+    base, query = _f32(xyz.detach().float()), _f32(new_xyz.detach().float())
     B, N, C = base.shape
     S = query.shape[1]
     dist = torch.empty(B, S, nsample, dtype=torch.float32, device=base.device)
@@ -345,8 +393,8 @@ class _IndexPoints(torch.autograd.Function):
         B, N, C = points.shape
         flat = idx.reshape(B, -1)
         M = flat.shape[1]
-        out = torch.empty(B, M, C, dtype=torch.float32, device=points.device)
-        _launch("mpa_gather_fwd_f32", _p(points), _p(flat), B, N, M, C, _p(out), _stream())
+        out = torch.empty(B, M, C, dtype=points.dtype, device=points.device)
+        _launch("mpa_gather_fwd_" + _sfx(points), _p(points), _p(flat), B, N, M, C, _p(out), _stream())
         ctx.save_for_backward(flat)
         ctx.shape = (B, N, M, C)
         return out.view(*idx.shape, C)
@@ -356,15 +404,16 @@ class _IndexPoints(torch.autograd.Function):
         (flat,) = ctx.saved_tensors
         B, N, M, C = ctx.shape
         grad = grad.contiguous()
+        # rows listed several times are summed in fp32 (float atomics on whole rows), whatever the storage type
         gp = torch.zeros(B, N, C, dtype=torch.float32, device=grad.device)
-        _launch("mpa_gather_bwd_f32", _p(grad), _p(flat), B, N, M, C, _p(gp), _stream())
-        return gp, None
+        _launch("mpa_gather_bwd_" + _sfx(grad), _p(grad), _p(flat), B, N, M, C, _p(gp), _stream())
+        return (gp if grad.dtype == torch.float32 else gp.to(grad.dtype)), None
 
 
 def index_points(points, idx, cuda=False, is_group=False):
     """reference: modules/pointnet2_utils.py:64-81.  points [B,N,C], idx [B,S] or [B,S,K]."""
     _dev(points, idx)
-    if points.dtype != torch.float32:
+    if points.dtype not in _FEATURE_DTYPES:
         # index-map composition etc. (integer payloads): plain device indexing
         B = points.shape[0]
         bidx = torch.arange(B, device=points.device).view([B] + [1] * (idx.dim() - 1)).expand_as(idx)
@@ -373,6 +422,11 @@ def index_points(points, idx, cuda=False, is_group=False):
 
 
 # ------------------------------------------------------------------------------- attention
+def _attn_ws_bytes(t, B, N, S, K, C):
+    fn = lib.mpa_diffattn_bwd_workspace_bytes_bf16 if t.dtype == torch.bfloat16 else lib.mpa_diffattn_bwd_workspace_bytes
+    return int(fn(B, N, S, K, C))
+
+
 class _DiffAttn(torch.autograd.Function):
     """ctx = max_j (softmax_j((q-k_j)/sqrt(C)) - sum) * v_j with k|v = the two halves of kv."""
 
@@ -381,12 +435,11 @@ class _DiffAttn(torch.autograd.Function):
         B, S, C = q.shape
         N = kv.shape[1]
         K = idx.shape[2]
+        es = q.element_size()
         out = torch.empty_like(q)
         argk = torch.empty(B, S, C, dtype=torch.uint8, device=q.device)
-        k = kv
-        v = kv[:, :, C:]
-        _launch("mpa_diffattn_fwd_f32", _p(q), C, _p(k), _vp(v.data_ptr()), 2 * C, _p(idx), B, N, S, K, C, _p(out),
-                _p(argk), _stream(), algo_bytes=B * S * (4 * (2 * C + 2 * K * C) + 8 * K + C))
+        _launch("mpa_diffattn_fwd_" + _sfx(q), _p(q), C, _p(kv), _vp(kv.data_ptr() + es * C), 2 * C, _p(idx), B, N, S, K, C,
+                _p(out), _p(argk), _stream(), algo_bytes=B * S * (es * (2 * C + 2 * K * C) + 8 * K + C))
         ctx.save_for_backward(q, kv, idx, argk)
         return out
 
@@ -396,15 +449,17 @@ class _DiffAttn(torch.autograd.Function):
         B, S, C = q.shape
         N = kv.shape[1]
         K = idx.shape[2]
+        es = q.element_size()
         grad = grad.contiguous()
         gq = torch.empty_like(q)
         gkv = torch.empty_like(kv)          # fully written by the kernels
         # per-slot gradients + inverted neighbour table: the atomic-free backward's scratch
-        need = int(lib.mpa_diffattn_bwd_workspace_bytes(B, N, S, K, C))
+        need = _attn_ws_bytes(q, B, N, S, K, C)
         ws = torch.empty(need, dtype=torch.uint8, device=q.device) if need else None
-        _launch("mpa_diffattn_bwd_f32", _p(q), C, _p(kv), _vp(kv.data_ptr() + 4 * C), 2 * C, _p(idx), _p(argk), _p(grad),
-                B, N, S, K, C, _p(gq), _p(gkv), _vp(gkv.data_ptr() + 4 * C), 2 * C, _p(ws), 0 if ws is None else ws.numel(), _stream(),
-                algo_bytes=B * S * (4 * (3 * C + 2 * K * C + C) + 8 * K + C))
+        _launch("mpa_diffattn_bwd_" + _sfx(q), _p(q), C, _p(kv), _vp(kv.data_ptr() + es * C), 2 * C, _p(idx), _p(argk),
+                _p(grad), B, N, S, K, C, _p(gq), _p(gkv), _vp(gkv.data_ptr() + es * C), 2 * C, _p(ws),
+                0 if ws is None else ws.numel(), _stream(),
+                algo_bytes=B * S * (es * (3 * C + 2 * K * C + C) + 8 * K + C))
         return gq, gkv, None
 
 
@@ -413,7 +468,7 @@ def diffattn(q, kv, idx):
     (modules/pointnet2_utils.py:558-569).  q [B,S,C]; kv [B,N,2C] = projected keys | values;
     idx [B,S,K] -> ctx [B,S,C]."""
     _dev(q, kv, idx)
-    return _DiffAttn.apply(_f32(q), _f32(kv), _i64(idx))
+    return _DiffAttn.apply(_feat(q), _feat(kv), _i64(idx))
 
 
 class _DiffAttnPair(torch.autograd.Function):
@@ -428,13 +483,15 @@ class _DiffAttnPair(torch.autograd.Function):
         C = C2 // 2
         N = kvkv.shape[1]
         K = idx1.shape[2]
+        es = qq.element_size()
         outs, argks = [], []
         for s_, idx in enumerate((idx1, idx2)):
-            out = torch.empty(B, S, C, dtype=torch.float32, device=qq.device)
+            out = torch.empty(B, S, C, dtype=qq.dtype, device=qq.device)
             argk = torch.empty(B, S, C, dtype=torch.uint8, device=qq.device)
-            _launch("mpa_diffattn_fwd_f32", _vp(qq.data_ptr() + 4 * C * s_), 2 * C, _vp(kvkv.data_ptr() + 8 * C * s_),
-                    _vp(kvkv.data_ptr() + 8 * C * s_ + 4 * C), 4 * C, _p(idx), B, N, S, K, C, _p(out), _p(argk),
-                    _stream(), algo_bytes=B * S * (4 * (2 * C + 2 * K * C) + 8 * K + C))
+            _launch("mpa_diffattn_fwd_" + _sfx(qq), _vp(qq.data_ptr() + es * C * s_), 2 * C,
+                    _vp(kvkv.data_ptr() + 2 * es * C * s_), _vp(kvkv.data_ptr() + 2 * es * C * s_ + es * C), 4 * C,
+                    _p(idx), B, N, S, K, C, _p(out), _p(argk), _stream(),
+                    algo_bytes=B * S * (es * (2 * C + 2 * K * C) + 8 * K + C))
             outs.append(out)
             argks.append(argk)
         ctx.save_for_backward(qq, kvkv, idx1, idx2, *argks)
@@ -447,35 +504,37 @@ class _DiffAttnPair(torch.autograd.Function):
         C = C2 // 2
         N = kvkv.shape[1]
         K = idx1.shape[2]
+        es = qq.element_size()
         gqq = torch.empty_like(qq)
         gkvkv = torch.empty_like(kvkv)          # every column block fully written by its stream
-        need = int(lib.mpa_diffattn_bwd_workspace_bytes(B, N, S, K, C))
+        need = _attn_ws_bytes(qq, B, N, S, K, C)
         for s_, (idx, argk, g) in enumerate(((idx1, a1, g1), (idx2, a2, g2))):
             ws = torch.empty(need, dtype=torch.uint8, device=qq.device) if need else None
-            _launch("mpa_diffattn_bwd_f32", _vp(qq.data_ptr() + 4 * C * s_), 2 * C, _vp(kvkv.data_ptr() + 8 * C * s_),
-                    _vp(kvkv.data_ptr() + 8 * C * s_ + 4 * C), 4 * C, _p(idx), _p(argk), _p(g.contiguous()), B, N, S, K,
-                    C, _vp(gqq.data_ptr() + 4 * C * s_), _vp(gkvkv.data_ptr() + 8 * C * s_),
-                    _vp(gkvkv.data_ptr() + 8 * C * s_ + 4 * C), 4 * C, _p(ws), 0 if ws is None else ws.numel(), _stream(),
-                    algo_bytes=B * S * (4 * (3 * C + 2 * K * C + C) + 8 * K + C))
+            _launch("mpa_diffattn_bwd_" + _sfx(qq), _vp(qq.data_ptr() + es * C * s_), 2 * C,
+                    _vp(kvkv.data_ptr() + 2 * es * C * s_), _vp(kvkv.data_ptr() + 2 * es * C * s_ + es * C), 4 * C,
+                    _p(idx), _p(argk), _p(g.contiguous()), B, N, S, K, C, _vp(gqq.data_ptr() + es * C * s_),
+                    _vp(gkvkv.data_ptr() + 2 * es * C * s_), _vp(gkvkv.data_ptr() + 2 * es * C * s_ + es * C), 4 * C,
+                    _p(ws), 0 if ws is None else ws.numel(), _stream(),
+                    algo_bytes=B * S * (es * (3 * C + 2 * K * C + C) + 8 * K + C))
         return gqq, gkvkv, None, None
 
 
 def diffattn_pair(qq, kvkv, idx1, idx2):
     """(ctx1, ctx2) of two difference-wise attentions on stacked projections (see _DiffAttnPair)."""
     _dev(qq, kvkv, idx1, idx2)
-    return _DiffAttnPair.apply(_f32(qq), _f32(kvkv), _i64(idx1), _i64(idx2))
+    return _DiffAttnPair.apply(_feat(qq), _feat(kvkv), _i64(idx1), _i64(idx2))
 
 
 class _DiffAttnXYZ(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, xyz, center, idx, Wq, bq, Wk, bk, Wv, bv):
+    def forward(ctx, xyz, center, idx, Wq, bq, Wk, bk, Wv, bv, out_dtype):
         B, N, _ = xyz.shape
         S, K = idx.shape[1], idx.shape[2]
         C = Wq.shape[0]
-        out = torch.empty(B, S, C, dtype=torch.float32, device=xyz.device)
+        out = torch.empty(B, S, C, dtype=out_dtype, device=xyz.device)
         argk = torch.empty(B, S, C, dtype=torch.uint8, device=xyz.device)
         params = [t.contiguous() for t in (Wq, bq, Wk, bk, Wv, bv)]
-        _launch("mpa_diffattn_xyz_fwd_f32", _p(xyz), _p(center), _p(idx), *[_p(t) for t in params], B, N, S, K, C,
+        _launch("mpa_diffattn_xyz_fwd_" + _sfx(out), _p(xyz), _p(center), _p(idx), *[_p(t) for t in params], B, N, S, K, C,
                                            _p(out), _p(argk), _stream())
         ctx.save_for_backward(xyz, center, idx, argk, *params)
         ctx.direct = tuple(_direct(t) for t in (Wq, bq, Wk, bk, Wv, bv))
@@ -491,17 +550,19 @@ class _DiffAttnXYZ(torch.autograd.Function):
         # the kernel accumulates with atomics: into the cleared flat gradients when installed
         # (GradReducer direct mode), else into fresh zero tensors
         gs = [d if d is not None else torch.zeros_like(t) for d, t in zip(ctx.direct, (Wq, bq, Wk, bk, Wv, bv))]
-        _launch("mpa_diffattn_xyz_bwd_f32", _p(xyz), _p(center), _p(idx), _p(Wq), _p(bq), _p(Wk), _p(bk), _p(Wv),
+        _launch("mpa_diffattn_xyz_bwd_" + _sfx(grad), _p(xyz), _p(center), _p(idx), _p(Wq), _p(bq), _p(Wk), _p(bk), _p(Wv),
                 _p(bv), _p(argk), _p(grad), B, N, S, K, C, *[_p(g) for g in gs], _stream())
-        return (None, None, None) + tuple(None if d is not None else g for d, g in zip(ctx.direct, gs))
+        return (None, None, None) + tuple(None if d is not None else g for d, g in zip(ctx.direct, gs)) + (None,)
 
 
 def diffattn_xyz(xyz, center, idx, Wq, bq, Wk, bk, Wv, bv):
     """LocalTrans' xyz branch (modules/pointnet2_utils.py:518-544) on raw coordinates:
     xyz [B,N,3] base, center [B,S,3], idx [B,S,K]; W* [C,3], b* [C] -> ctx [B,S,C].
-    Coordinates are network inputs and receive no gradient."""
+    Coordinates are network inputs and receive no gradient.  The context is emitted in FEATURE_DTYPE: this is
+    where the feature stream of a model starts."""
     _dev(xyz, center, idx, Wq)
-    return _DiffAttnXYZ.apply(_f32(xyz.detach()), _f32(center.detach()), _i64(idx), Wq, bq, Wk, bk, Wv, bv)
+    return _DiffAttnXYZ.apply(_f32(xyz.detach()), _f32(center.detach()), _i64(idx), Wq, bq, Wk, bk, Wv, bv,
+                              FEATURE_DTYPE)
 
 
 # ------------------------------------------------------------------------------- decoder
@@ -510,11 +571,11 @@ class _UpsampleMean(torch.autograd.Function):
     def forward(ctx, points, knn_idx, n_fine):
         B, S, C = points.shape
         K = knn_idx.shape[2]
-        out = torch.empty(B, n_fine, C, dtype=torch.float32, device=points.device)
+        out = torch.empty(B, n_fine, C, dtype=points.dtype, device=points.device)
         cnt = torch.empty(B, n_fine, dtype=torch.float32, device=points.device)
-        nbytes = int(lib.mpa_upsample_workspace_bytes(B, S, K, n_fine))      # 0: atomic scatter path
+        nbytes = int(lib.mpa_upsample_workspace_bytes(B, S, K, n_fine))      # 0: atomic scatter path (fp32 only)
         ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=points.device)
-        _launch("mpa_upsample_mean_fwd_f32", _p(points), _p(knn_idx), B, S, K, n_fine, C, _p(out), _p(cnt),
+        _launch("mpa_upsample_mean_fwd_" + _sfx(points), _p(points), _p(knn_idx), B, S, K, n_fine, C, _p(out), _p(cnt),
                 _p(ws) if nbytes else None, nbytes, _stream())
         ctx.save_for_backward(knn_idx, cnt)
         ctx.shape = (B, S, K, n_fine, C)
@@ -525,8 +586,8 @@ class _UpsampleMean(torch.autograd.Function):
         knn_idx, cnt = ctx.saved_tensors
         B, S, K, n_fine, C = ctx.shape
         grad = grad.contiguous()
-        gp = torch.empty(B, S, C, dtype=torch.float32, device=grad.device)
-        _launch("mpa_upsample_mean_bwd_f32", _p(grad), _p(knn_idx), _p(cnt), B, S, K, n_fine, C, _p(gp), _stream())
+        gp = torch.empty(B, S, C, dtype=grad.dtype, device=grad.device)
+        _launch("mpa_upsample_mean_bwd_" + _sfx(grad), _p(grad), _p(knn_idx), _p(cnt), B, S, K, n_fine, C, _p(gp), _stream())
         return gp, None, None
 
 
@@ -537,7 +598,7 @@ def upsample(points, knn_idx, scale_ratio=2, dist=None):
     the reference, that dependence is not differentiated."""
     _dev(points, knn_idx)
     n_fine = points.shape[1] * scale_ratio
-    return _UpsampleMean.apply(_f32(points), _i64(knn_idx), n_fine)
+    return _UpsampleMean.apply(_feat(points), _i64(knn_idx), n_fine)
 
 
 class _ThreeInterp(torch.autograd.Function):
@@ -587,6 +648,8 @@ def _workspace(device, nbytes):
 
 
 def _gemm(A, lda, tA, Bm, ldb, tB, bias, C, ldc, M, N, K, accumulate=0, tile_stats=None, a_col_sum=None):
+    if A.dtype == torch.bfloat16:
+        return _gemm_bf16(A, lda, tA, Bm, ldb, tB, bias, C, ldc, M, N, K, accumulate, tile_stats, a_col_sum)
     ws, ws_bytes = None, 0
     ntiles = ((M + 63) // 64) * ((N + 63) // 64)
     if ntiles < 256 and K >= 512 and ldc == N:          # split-K partial tiles (see mpa_gemm_f32)
@@ -601,6 +664,45 @@ def _gemm(A, lda, tA, Bm, ldb, tB, bias, C, ldc, M, N, K, accumulate=0, tile_sta
             _p(tile_stats), _p(a_col_sum), _p(ws), ws_bytes, _stream(), algo_bytes=4 * (M * K + N * K + M * N),
             algo_flops=2 * M * N * K, tag=(M, N, K, tA, tB, tile_stats is not None),
             variant="shortk" if shortk else "tiled")
+
+
+def _gemm_bf16(A, lda, tA, Bm, ldb, tB, bias, C, ldc, M, N, K, accumulate, tile_stats, a_col_sum):
+    """The same products on bf16 features (mpa_gemm_bf16 / mpa_gemm_tn_grouped_bf16): A is a bf16 activation or
+    gradient; B the fp32 master weight (forward, dX) or a bf16 activation (dW); C bf16, or fp32 for logits
+    and weight gradients."""
+    if accumulate:
+        raise NotImplementedError("bf16 products do not accumulate into C")
+    if tA:                                          # dW = A^T B: one problem of the grouped launch
+        if tB or Bm.dtype != torch.bfloat16 or C.dtype != torch.float32 or ldc != N:
+            raise NotImplementedError("bf16 A^T B needs bf16 k-major operands and a dense fp32 output")
+        _weight_grads_bf16([(A, lda, Bm, ldb, C, M, N, K, a_col_sum)])
+        return
+    if a_col_sum is not None:
+        raise NotImplementedError("column sums ride on the weight-gradient product only")
+    b32 = Bm.dtype == torch.float32
+    c32 = C.dtype == torch.float32
+    _launch("mpa_gemm_bf16", _p(A), lda, _p(Bm), ldb, 1 if tB else 0, int(b32), _p(bias), _p(C), ldc, int(c32), M, N, K,
+            _p(tile_stats), _stream(), algo_bytes=2 * M * K + (4 if b32 else 2) * N * K + (4 if c32 else 2) * M * N,
+            algo_flops=2 * M * N * K, tag=(M, N, K, tA, tB, tile_stats is not None))
+
+
+def _weight_grads_bf16(queue):
+    """queue entries: (gy, lda, x, ldb, out, M, N, K, a_col_sum) with bf16 gy / x and fp32 out."""
+    n = len(queue)
+    arr = (GemmTnProblemBf16 * n)()
+    ws_bytes = 0
+    for i, (gy, lda, x, ldb, out, M, N, K, acs) in enumerate(queue):
+        arr[i].A, arr[i].B, arr[i].out = gy.data_ptr(), x.data_ptr(), out.data_ptr()
+        arr[i].a_col_sum = acs.data_ptr() if acs is not None else None
+        arr[i].lda, arr[i].ldb, arr[i].M, arr[i].N, arr[i].K = lda, ldb, M, N, K
+        tiles = ((M + 63) // 64) * ((N + 63) // 64)
+        if tiles < 256 and K >= 2048:
+            splits = max(1, min((512 + tiles - 1) // tiles, K // 1024))
+            ws_bytes += (splits * M * N * 4 + 255) // 256 * 256
+    ws = _workspace(queue[0][0].device, max(ws_bytes, 4))
+    _launch("mpa_gemm_tn_grouped_bf16", arr, n, _p(ws), ws.numel() * 4, _stream(),
+            algo_bytes=sum(2 * q[7] * (q[5] + q[6]) + 4 * q[5] * q[6] for q in queue),
+            algo_flops=sum(2 * q[5] * q[6] * q[7] for q in queue))
 
 
 _ZEROS = {}
@@ -644,30 +746,37 @@ def _weight_grad(gy, lda, x, ldb, out, M, N, K, a_col_sum=None, direct=False):
 
 
 def flush_weight_grads():
-    """Issue every queued weight-gradient product as one grouped launch (+ one reduce)."""
+    """Issue every queued weight-gradient product as one grouped launch (+ one reduce) per storage type."""
     if not _DW_QUEUE:
         return
-    n = len(_DW_QUEUE)
-    arr = (GemmTnProblem * n)()
-    ws_bytes = 0
-    for i, (gy, lda, x, ldb, out, M, N, K, acs) in enumerate(_DW_QUEUE):
-        arr[i].A, arr[i].B, arr[i].out = gy.data_ptr(), x.data_ptr(), out.data_ptr()
-        arr[i].a_col_sum = acs.data_ptr() if acs is not None else None
-        arr[i].lda, arr[i].ldb, arr[i].M, arr[i].N, arr[i].K = lda, ldb, M, N, K
-        tiles = ((M + 63) // 64) * ((N + 63) // 64)
-        if tiles < 256 and K >= 512:
-            splits = max(1, min((512 + tiles - 1) // tiles, K // 256))
-            ws_bytes += (splits * M * N * 4 + 255) // 256 * 256
-    dev = _DW_QUEUE[0][0].device
-    ws = _workspace(dev, max(ws_bytes, 4))
-    _launch("mpa_gemm_tn_grouped_f32", arr, n, _p(ws), ws.numel() * 4, _stream(),
-            algo_bytes=sum(4 * (q[7] * (q[5] + q[6]) + q[5] * q[6]) for q in _DW_QUEUE),
-            algo_flops=sum(2 * q[5] * q[6] * q[7] for q in _DW_QUEUE))
+    q16 = [q for q in _DW_QUEUE if q[0].dtype == torch.bfloat16]
+    q32 = [q for q in _DW_QUEUE if q[0].dtype != torch.bfloat16]
+    if q16:
+        _weight_grads_bf16(q16)
+    if q32:
+        n = len(q32)
+        arr = (GemmTnProblem * n)()
+        ws_bytes = 0
+        for i, (gy, lda, x, ldb, out, M, N, K, acs) in enumerate(q32):
+            arr[i].A, arr[i].B, arr[i].out = gy.data_ptr(), x.data_ptr(), out.data_ptr()
+            arr[i].a_col_sum = acs.data_ptr() if acs is not None else None
+            arr[i].lda, arr[i].ldb, arr[i].M, arr[i].N, arr[i].K = lda, ldb, M, N, K
+            tiles = ((M + 63) // 64) * ((N + 63) // 64)
+            if tiles < 256 and K >= 512:
+                splits = max(1, min((512 + tiles - 1) // tiles, K // 256))
+                ws_bytes += (splits * M * N * 4 + 255) // 256 * 256
+        dev = q32[0][0].device
+        ws = _workspace(dev, max(ws_bytes, 4))
+        _launch("mpa_gemm_tn_grouped_f32", arr, n, _p(ws), ws.numel() * 4, _stream(),
+                algo_bytes=sum(4 * (q[7] * (q[5] + q[6]) + q[5] * q[6]) for q in q32),
+                algo_flops=sum(2 * q[5] * q[6] * q[7] for q in q32))
     _DW_QUEUE.clear()
 
 
 def _col_sum(x2d, ld=None):
     M, C = x2d.shape
+    if x2d.dtype != torch.float32:
+        return x2d.float().sum(0)
     out = torch.zeros(C, dtype=torch.float32, device=x2d.device)
     _launch("mpa_col_sum_f32", _p(x2d), M, C, C if ld is None else ld, _p(out), _stream())
     return out
@@ -676,6 +785,9 @@ def _col_sum(x2d, ld=None):
 def _col_sum_into(x2d, out, ld=None):
     """out[C] += column sums of x2d (out is a cleared flat-gradient view)."""
     M, C = x2d.shape
+    if x2d.dtype != torch.float32:
+        out.add_(x2d.float().sum(0))
+        return
     _launch("mpa_col_sum_f32", _p(x2d), M, C, C if ld is None else ld, _p(out), _stream())
 
 
@@ -701,10 +813,10 @@ class _Linear(torch.autograd.Function):
     of the difference attention: a shift of q or of every k_j leaves the softmax unchanged)."""
 
     @staticmethod
-    def forward(ctx, x, W, b, bias_grad_is_zero):
+    def forward(ctx, x, W, b, bias_grad_is_zero, out_dtype=None):
         M, K = x.shape
         N = W.shape[0]
-        y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+        y = torch.empty(M, N, dtype=out_dtype or x.dtype, device=x.device)
         _gemm(x, K, 0, W, K, 1, b, y, N, M, N, K)
         ctx.save_for_backward(x, W)
         ctx.has_bias = b is not None
@@ -717,11 +829,13 @@ class _Linear(torch.autograd.Function):
         x, W = ctx.saved_tensors
         M, K = x.shape
         N = W.shape[0]
+        if gy.dtype != x.dtype:
+            gy = gy.to(x.dtype)             # fp32 logits of a bf16 model: their gradient joins the bf16 stream
         gy, ldg = _rows_ld(gy)
         dW, db = ctx.direct
         gx = gW = gb = None
         if ctx.needs_input_grad[0]:
-            gx = torch.empty(M, K, dtype=torch.float32, device=x.device)
+            gx = torch.empty(M, K, dtype=x.dtype, device=x.device)
             _gemm(gy, ldg, 0, W, K, 0, None, gx, K, M, K, N)          # gy [M,N] @ W [N,K]
         want_b = ctx.has_bias and ctx.needs_input_grad[2] and not ctx.zero_bias
         gb_buf = None
@@ -740,14 +854,15 @@ class _Linear(torch.autograd.Function):
                 gb = None if db is not None else _zeros_like_cached(x.device, N)
             else:
                 gb = None if db is not None else gb_buf
-        return gx, gW, gb, None
+        return gx, gW, gb, None, None
 
 
-def linear(x, weight, bias, bias_grad_is_zero=False):
-    """y = x W^T + b over the last dimension (nn.Linear), any leading shape."""
+def linear(x, weight, bias, bias_grad_is_zero=False, out_dtype=None):
+    """y = x W^T + b over the last dimension (nn.Linear), any leading shape.  out_dtype=torch.float32 on
+    bf16 features: the product's fp32 results are stored unrounded (logits handed to a loss)."""
     _dev(x, weight)
     lead = x.shape[:-1]
-    y = _Linear.apply(_f32(x).reshape(-1, x.shape[-1]), _f32(weight), bias, bias_grad_is_zero)
+    y = _Linear.apply(_feat(x).reshape(-1, x.shape[-1]), _f32(weight), bias, bias_grad_is_zero, out_dtype)
     return y.view(*lead, weight.shape[0])
 
 
@@ -775,7 +890,7 @@ class _LinearKV(torch.autograd.Function):
         # (optim.FlatAdam's flat parameter buffers keep LocalTrans' k|v pairs adjacent)
         Wkv = _stacked(Wk, Wv)
         bkv = _stacked(bk, bv)
-        kv = torch.empty(M, 2 * C, dtype=torch.float32, device=x.device)
+        kv = torch.empty(M, 2 * C, dtype=x.dtype, device=x.device)
         _gemm(x, K, 0, Wkv, K, 1, bkv, kv, 2 * C, M, 2 * C, K)
         ctx.save_for_backward(x, Wkv)
         ctx.direct = (_direct(Wk), _direct(bk), _direct(Wv), _direct(bv))
@@ -791,7 +906,7 @@ class _LinearKV(torch.autograd.Function):
         dWk, dbk, dWv, dbv = ctx.direct
         gx = None
         if ctx.needs_input_grad[0]:
-            gx = torch.empty(M, K, dtype=torch.float32, device=dev)
+            gx = torch.empty(M, K, dtype=x.dtype, device=dev)
             _gemm(gkv, 2 * C, 0, Wkv, K, 0, None, gx, K, M, K, 2 * C)
         gv_view = gkv[:, C:]
         gWk = dWk if dWk is not None else torch.empty(C, K, dtype=torch.float32, device=dev)
@@ -810,7 +925,7 @@ def linear_kv(x, k_lin, v_lin):
     """Projected keys | values [.., 2C] of LocalTrans' feature branch from the two nn.Linear."""
     _dev(x, k_lin.weight)
     lead = x.shape[:-1]
-    kv = _LinearKV.apply(_f32(x).reshape(-1, x.shape[-1]), k_lin.weight, k_lin.bias, v_lin.weight, v_lin.bias)
+    kv = _LinearKV.apply(_feat(x).reshape(-1, x.shape[-1]), k_lin.weight, k_lin.bias, v_lin.weight, v_lin.bias)
     return kv.view(*lead, kv.shape[-1])
 
 
@@ -837,7 +952,7 @@ class _LinearStack(torch.autograd.Function):
         M, K = x.shape
         Wst, bst = _stacked_all(Ws), _stacked_all(bs)
         Nt = Wst.shape[0]
-        y = torch.empty(M, Nt, dtype=torch.float32, device=x.device)
+        y = torch.empty(M, Nt, dtype=x.dtype, device=x.device)
         _gemm(x, K, 0, Wst, K, 1, bst, y, Nt, M, Nt, K)
         ctx.save_for_backward(x, Wst)
         ctx.sizes = [w.shape[0] for w in Ws]
@@ -854,7 +969,7 @@ class _LinearStack(torch.autograd.Function):
         gy, ldg = _rows_ld(gy)
         gx = None
         if ctx.needs_input_grad[0]:
-            gx = torch.empty(M, K, dtype=torch.float32, device=dev)
+            gx = torch.empty(M, K, dtype=x.dtype, device=dev)
             _gemm(gy, ldg, 0, Wst, K, 0, None, gx, K, M, K, Nt)
         grads = []
         off = 0
@@ -880,7 +995,7 @@ def linear_stack(x, layers, zero_bias):
     wb = []
     for l in layers:
         wb += [l.weight, l.bias]
-    y = _LinearStack.apply(_f32(x).reshape(-1, x.shape[-1]), tuple(zero_bias), *wb)
+    y = _LinearStack.apply(_feat(x).reshape(-1, x.shape[-1]), tuple(zero_bias), *wb)
     return y.view(*lead, y.shape[-1])
 
 
@@ -897,10 +1012,10 @@ class _LinearBNAct(torch.autograd.Function):
         M, K = x.shape
         N = W.shape[0]
         dev = x.device
-        y = torch.empty(M, N, dtype=torch.float32, device=dev)
+        y = torch.empty(M, N, dtype=x.dtype, device=dev)
         stats = torch.empty((M + 63) // 64, 2, N, dtype=torch.float32, device=dev) if training else None
         _gemm(x, K, 0, W, K, 1, b, y, N, M, N, K, 0, stats)
-        out = torch.empty(M, N, dtype=torch.float32, device=dev)
+        out = torch.empty(M, N, dtype=x.dtype, device=dev)
         saved = torch.empty(2, N, dtype=torch.float32, device=dev)
         direct = (_direct(W), _direct(b), _direct(gamma), _direct(beta))
         need = any(ctx.needs_input_grad)
@@ -909,7 +1024,7 @@ class _LinearBNAct(torch.autograd.Function):
         sums = torch.empty(_BN_REPLICAS, 2, N, dtype=torch.float32, device=dev) if need else None
         _launch("mpa_bn_finalize_f32", _p(stats), M, N, _p(running_mean), _p(running_var), int(training),
                 float(momentum), float(eps), _p(saved), _p(sums), _BN_REPLICAS * 2 * N, _p(nbt), _stream())
-        _launch("mpa_bn_act_fwd_f32", _p(y), _p(saved), _p(gamma), _p(beta), _p(residual), float(slope), M, N,
+        _launch("mpa_bn_act_fwd_" + _sfx(y), _p(y), _p(saved), _p(gamma), _p(beta), _p(residual), float(slope), M, N,
                 _p(out), _stream())
         ctx.save_for_backward(x, W, y, gamma, beta, saved, sums)
         ctx.cfg = (bool(training), float(slope), b is not None, residual is not None)
@@ -929,17 +1044,17 @@ class _LinearBNAct(torch.autograd.Function):
         if ctx.ran_backward:            # double backward through the same node: accumulator is dirty
             sums = torch.zeros(_BN_REPLICAS, 2, N, dtype=torch.float32, device=dev)
         ctx.ran_backward = True
-        _launch("mpa_bn_act_bwd_reduce_f32", _p(y), _p(gout), _p(saved[0]), _p(saved[1]), _p(gamma), _p(beta), slope,
+        _launch("mpa_bn_act_bwd_reduce_" + _sfx(y), _p(y), _p(gout), _p(saved[0]), _p(saved[1]), _p(gamma), _p(beta), slope,
                 M, N, ldg, _p(sums), _BN_REPLICAS, _stream())
-        gy = torch.empty(M, N, dtype=torch.float32, device=dev)
+        gy = torch.empty(M, N, dtype=y.dtype, device=dev)
         # dgamma / dbeta: stored by the apply pass, straight into the flat gradients when installed
         gg = dgamma if dgamma is not None else torch.empty(N, dtype=torch.float32, device=dev)
         gb_ = dbeta if dbeta is not None else torch.empty(N, dtype=torch.float32, device=dev)
-        _launch("mpa_bn_act_bwd_apply_f32", _p(y), _p(gout), _p(saved[0]), _p(saved[1]), _p(gamma), _p(beta),
+        _launch("mpa_bn_act_bwd_apply_" + _sfx(y), _p(y), _p(gout), _p(saved[0]), _p(saved[1]), _p(gamma), _p(beta),
                 _p(sums), _BN_REPLICAS, slope, int(training), M, N, ldg, _p(gy), _p(gg), _p(gb_), _stream())
         gx = gW = gb = None
         if ctx.needs_input_grad[0]:
-            gx = torch.empty(M, K, dtype=torch.float32, device=dev)
+            gx = torch.empty(M, K, dtype=x.dtype, device=dev)
             _gemm(gy, N, 0, W, K, 0, None, gx, K, M, K, N)
         if ctx.needs_input_grad[1]:
             gW = dW if dW is not None else torch.empty(N, K, dtype=torch.float32, device=dev)
@@ -969,12 +1084,12 @@ def linear_bn_act(x, weight, bias, bn, slope, residual=None):
     the same kernel (LocalTrans' `residual + ffn(context)`, Fuse's `conv(x) + f`)."""
     _dev(x, weight)
     lead = x.shape[:-1]
-    x2 = _f32(x).reshape(-1, x.shape[-1])
+    x2 = _feat(x).reshape(-1, x.shape[-1])
     training = bn.training or bn.running_mean is None
     if training and x2.shape[0] <= 1:
         raise ValueError("Expected more than 1 value per channel when training (BatchNorm1d)")
     momentum = 0.1 if bn.momentum is None else bn.momentum
-    res2 = None if residual is None else _f32(residual).reshape(-1, weight.shape[0])
+    res2 = None if residual is None else _feat(residual).to(x2.dtype).reshape(-1, weight.shape[0])
     out = _LinearBNAct.apply(x2, _f32(weight), bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                              bn.num_batches_tracked if training else None, res2, training, momentum, bn.eps,
                              1.0 if slope is None else slope)
