@@ -193,6 +193,11 @@ int mpa_bn_act_fwd_f32(const float *x, const float *save_mean_invstd, const floa
                        const float *residual, float slope, int M, int C, float *y, void *stream);
 /* out[c] += sum over the M rows of x[r*ld + c]  (bias gradients; out [C] cleared by the caller). */
 int mpa_col_sum_f32(const float *x, int M, int C, int ld, float *out, void *stream);
+/* out[g][c] = sum over the R rows of group g of x[(g*R + r)*ld + c], x [G*R, >= C] (leading dimension ld), out [G,C]
+ * fp32, fully written (no atomics, no clearing): the gradient of a per-cloud row broadcast over the cloud's
+ * points -- the global-feature and label-embedding columns the part-seg head concatenates to every point
+ * (modules/pointnet2_utils.py:846-856). */
+int mpa_group_col_sum_f32(const float *x, int G, int R, int C, int ld, float *out, void *stream);
 /* backward of y = lrelu(bn(x)).  Pass 1 accumulates, with float atomics spread over `replicas`
  * copies, partial[r][0][c] += sum g and partial[r][1][c] += sum g*xhat (g = grad_y * lrelu'(.);
  * partial [replicas][2][C] pre-zeroed, e.g. by mpa_bn_finalize_f32's zero_buf).  Pass 2 sums the
@@ -341,6 +346,7 @@ int mpa_upsample_mean_fwd_bf16(const mpa_bf16 *points, const int64_t *knn_idx, i
 int mpa_upsample_mean_bwd_bf16(const mpa_bf16 *grad_out, const int64_t *knn_idx, const float *cnt,
                                int B, int S, int K, int Nf, int C, mpa_bf16 *grad_points,
                                void *stream);
+int mpa_group_col_sum_bf16(const mpa_bf16 *x, int G, int R, int C, int ld, float *out, void *stream);
 /*BF16_MORE*/
 
 #ifdef __cplusplus

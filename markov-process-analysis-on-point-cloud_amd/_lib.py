@@ -47,6 +47,7 @@ SIGNATURES = {
     "mpa_col_stats_f32": [_vp, _i, _i, _vp, _vp, _vp],
     "mpa_bn_act_fwd_f32": [_vp, _vp, _vp, _vp, _vp, _f, _i, _i, _vp, _vp],
     "mpa_col_sum_f32": [_vp, _i, _i, _i, _vp, _vp],
+    "mpa_group_col_sum_f32": [_vp, _i, _i, _i, _i, _vp, _vp],
     "mpa_bn_act_bwd_reduce_f32": [_vp] * 6 + [_f, _i, _i, _i, _vp, _i, _vp],
     "mpa_bn_act_bwd_apply_f32": [_vp] * 7 + [_i, _f, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "mpa_scalar_add_f32": [_vp, _f, _vp],
@@ -89,6 +90,7 @@ SIGNATURES.update({
     "mpa_diffattn_xyz_bwd_bf16": SIGNATURES["mpa_diffattn_xyz_bwd_f32"],
     "mpa_upsample_mean_fwd_bf16": SIGNATURES["mpa_upsample_mean_fwd_f32"],
     "mpa_upsample_mean_bwd_bf16": SIGNATURES["mpa_upsample_mean_bwd_f32"],
+    "mpa_group_col_sum_bf16": SIGNATURES["mpa_group_col_sum_f32"],
 })
 
 for _name, _args in SIGNATURES.items():

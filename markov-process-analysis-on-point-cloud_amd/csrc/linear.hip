@@ -829,6 +829,37 @@ __global__ __launch_bounds__(256) void col_sum_kernel(const float *__restrict__ 
     }
 }
 
+
+// out[g][c] = sum over the R rows of group g of x[(g*R + r)*ld + c]: the gradient of a per-cloud row that was
+// broadcast over the cloud's points (the global-feature / label-embedding columns of the part-seg head,
+// reference modules/pointnet2_utils.py:846-856).  One workgroup per (group, 64 columns): 4 row lanes x 64
+// column lanes, fp32 accumulation, combined through LDS, plain stores -- no atomics, nothing to clear, and no
+// multi-workgroup reduction (torch's own, which autograd would use for expand(), is what goes wrong under
+// HIP-graph replay on this stack: DESIGN.md section 5).
+template <typename T>
+__global__ __launch_bounds__(256) void group_col_sum_kernel(const T *__restrict__ x, int R, int C, int ld,
+                                                            float *__restrict__ out)
+{
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int g = blockIdx.y, c = blockIdx.x * 64 + cl;
+    const T *base = x + (size_t)g * R * ld;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (c < C) {
+        int r = rl;
+        for (; r + 12 < R; r += 16) {
+            a0 += mpa_ld1<T>(base + (size_t)r * ld + c);
+            a1 += mpa_ld1<T>(base + (size_t)(r + 4) * ld + c);
+            a2 += mpa_ld1<T>(base + (size_t)(r + 8) * ld + c);
+            a3 += mpa_ld1<T>(base + (size_t)(r + 12) * ld + c);
+        }
+        for (; r < R; r += 4) a0 += mpa_ld1<T>(base + (size_t)r * ld + c);
+    }
+    red[rl][cl] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (rl == 0 && c < C) out[(size_t)g * C + c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+}
+
 // Column reductions over the M rows of an [M,C] tensor.  A workgroup owns a slab of rows and
 // a group of <= 256 channels; its 256 lanes are arranged [RY][CPB] (channel fastest: coalesced
 // rows), each lane walks its rows 4 at a time (independent loads in flight), the RY partials
@@ -1394,4 +1425,25 @@ extern "C" int mpa_bn_act_bwd_apply_bf16(const mpa_bf16 *x, const mpa_bf16 *grad
     return bn_act_bwd_apply_any<bf16_t>(reinterpret_cast<const bf16_t *>(x), reinterpret_cast<const bf16_t *>(grad_y), mean,
                                         invstd, gamma, beta, partial, replicas, slope, use_batch_stats, M, C, ldg,
                                         reinterpret_cast<bf16_t *>(grad_x), dgamma, dbeta, stream);
+}
+
+template <typename T>
+static int group_col_sum_any(const T *x, int G, int R, int C, int ld, float *out, void *stream)
+{
+    MPA_CLEAR_ERROR();
+    if (!x || !out || G <= 0 || R <= 0 || C <= 0 || ld < C || G > 65535) return MPA_EINVAL;
+    hipLaunchKernelGGL(group_col_sum_kernel<T>, dim3(mpa_ceil_div(C, 64), G), dim3(256), 0, (hipStream_t)stream, x, R, C,
+                       ld, out);
+    MPA_LAUNCH_CHECK();
+    return MPA_OK;
+}
+
+extern "C" int mpa_group_col_sum_f32(const float *x, int G, int R, int C, int ld, float *out, void *stream)
+{
+    return group_col_sum_any<float>(x, G, R, C, ld, out, stream);
+}
+
+extern "C" int mpa_group_col_sum_bf16(const mpa_bf16 *x, int G, int R, int C, int ld, float *out, void *stream)
+{
+    return group_col_sum_any<bf16_t>(reinterpret_cast<const bf16_t *>(x), G, R, C, ld, out, stream);
 }

@@ -90,6 +90,123 @@ __device__ __forceinline__ bf16x8_t tr_frag(const char *img, int kb, int cbase, 
 // columns = 2 x (BN/64) accumulator tiles of 32 x 32, and its 64 rows are exactly one 64-row tile of the
 // BatchNorm statistics format (tile_stats [ceil(M/64)][2][N]: sum, sum of squared deviations from the tile
 // mean), which therefore come out of the accumulators with one cross-half shuffle and no LDS.
+//
+// (Staging helpers are free functions taking the register arrays by reference: as lambdas capturing the
+//  arrays, two instantiations kept them in scratch memory -- 320 B per lane, every slab through it -- and ran
+//  3.7x slower than their twins.)
+template <int BN> struct GemmCfg {
+    static constexpr int NJ = BN / 64;                    // accumulator tiles per wave along N
+    static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, BUF = A_BYTES + B_BYTES;
+    static constexpr int BCH = BN * BK / 8 / NT;          // 16-B chunks of a B slab per lane
+};
+
+template <bool INTERIOR, bool TB, int BN, typename TBm>
+__device__ __forceinline__ void gemm_load_slab(const bf16_t *__restrict__ A, int lda, const TBm *__restrict__ Bm,
+                                               int ldb, int m0, int n0, int k0, int M, int N, int K, int vecA,
+                                               int vecB, int tid, uint4 (&ra)[4], uint4 (&rb)[GemmCfg<BN>::BCH])
+{
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {                                            // A: 128 rows x 8 chunks
+        const int i = tid + NT * q, row = i >> 3, ch = i & 7;
+        const bf16_t *p = A + (size_t)(m0 + row) * lda + k0 + ch * 8;
+        if constexpr (INTERIOR) ra[q] = load8(p);
+        else {
+            const int nv = (m0 + row < M) ? min(8, max(0, K - (k0 + ch * 8))) : 0;
+            ra[q] = (vecA && nv == 8) ? load8(p) : load8_guard(p, nv);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < GemmCfg<BN>::BCH; ++q) {
+        const int i = tid + NT * q;
+        if constexpr (TB) {                                                  // B [N][K]: BN rows x 8 chunks
+            const int row = i >> 3, ch = i & 7;
+            const TBm *p = Bm + (size_t)(n0 + row) * ldb + k0 + ch * 8;
+            if constexpr (INTERIOR) rb[q] = load8(p);
+            else {
+                const int nv = (n0 + row < N) ? min(8, max(0, K - (k0 + ch * 8))) : 0;
+                rb[q] = (vecB && nv == 8) ? load8(p) : load8_guard(p, nv);
+            }
+        } else {                                                             // B [K][N]: 64 k rows x BN/8 chunks
+            const int kr = i / (BN / 8), cc = i % (BN / 8);
+            const TBm *p = Bm + (size_t)(k0 + kr) * ldb + n0 + cc * 8;
+            if constexpr (INTERIOR) rb[q] = load8(p);
+            else {
+                const int nv = (k0 + kr < K) ? min(8, max(0, N - (n0 + cc * 8))) : 0;
+                rb[q] = (vecB && nv == 8) ? load8(p) : load8_guard(p, nv);
+            }
+        }
+    }
+}
+
+template <bool TB, int BN>
+__device__ __forceinline__ void gemm_store_slab(char *buf, int tid, const uint4 (&ra)[4],
+                                                const uint4 (&rb)[GemmCfg<BN>::BCH])
+{
+    char *As = buf, *Bs = buf + GemmCfg<BN>::A_BYTES;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i = tid + NT * q;
+        *reinterpret_cast<uint4 *>(As + kc_off(i >> 3, i & 7)) = ra[q];
+    }
+#pragma unroll
+    for (int q = 0; q < GemmCfg<BN>::BCH; ++q) {
+        const int i = tid + NT * q;
+        if constexpr (TB) *reinterpret_cast<uint4 *>(Bs + kc_off(i >> 3, i & 7)) = rb[q];
+        else *reinterpret_cast<uint4 *>(Bs + km_off<BN>(i / (BN / 8), (i % (BN / 8)) * 8)) = rb[q];
+    }
+}
+
+template <bool TB, int BN>
+__device__ __forceinline__ void gemm_multiply(const char *buf, int wm, int wn, int lane,
+                                              floatx16 (&acc)[2][GemmCfg<BN>::NJ])
+{
+    constexpr int NJ = GemmCfg<BN>::NJ;
+    const int half = lane >> 5, r31 = lane & 31;
+    const char *As = buf, *Bs = buf + GemmCfg<BN>::A_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+        bf16x8_t a[2], b[NJ];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            a[i] = *reinterpret_cast<const bf16x8_t *>(As + kc_off(wm * 64 + i * 32 + r31, 2 * ks + half));
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            if constexpr (TB)
+                b[j] = *reinterpret_cast<const bf16x8_t *>(Bs + kc_off(wn * (BN / 2) + j * 32 + r31, 2 * ks + half));
+            else
+                b[j] = tr_frag<BN>(Bs, 16 * ks + 8 * half, wn * (BN / 2) + j * 32, lane);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+}
+
+template <bool INTERIOR, bool TB, int BN, typename TBm>
+__device__ __forceinline__ void gemm_main_loop(const bf16_t *__restrict__ A, int lda, const TBm *__restrict__ Bm,
+                                               int ldb, int m0, int n0, int M, int N, int K, int vecA, int vecB,
+                                               char *smem, floatx16 (&acc)[2][GemmCfg<BN>::NJ])
+{
+    constexpr int BUF = GemmCfg<BN>::BUF;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int nslab = (K + BK - 1) / BK;
+    uint4 ra[4], rb[GemmCfg<BN>::BCH];
+    gemm_load_slab<INTERIOR, TB, BN, TBm>(A, lda, Bm, ldb, m0, n0, 0, M, N, K, vecA, vecB, tid, ra, rb);
+    gemm_store_slab<TB, BN>(smem, tid, ra, rb);
+    __syncthreads();
+    for (int s = 0; s < nslab; ++s) {
+        char *cur = smem + (s & 1) * BUF, *nxt = smem + ((s + 1) & 1) * BUF;
+        if (s + 1 < nslab)                                    // next slab's loads fly during the MFMAs
+            gemm_load_slab<INTERIOR, TB, BN, TBm>(A, lda, Bm, ldb, m0, n0, (s + 1) * BK, M, N, K, vecA, vecB, tid, ra, rb);
+        gemm_multiply<TB, BN>(cur, wm, wn, lane, acc);
+        if (s + 1 < nslab) gemm_store_slab<TB, BN>(nxt, tid, ra, rb);
+        __syncthreads();
+    }
+}
+
 template <bool TB, int BN, typename TBm, bool OUT_F32>
 __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const bf16_t *__restrict__ A, int lda,
                                                           const TBm *__restrict__ Bm, int ldb,
@@ -97,9 +214,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const bf16_t *__restri
                                                           int M, int N, int K, float *__restrict__ tile_stats,
                                                           int vecA, int vecB, int vecC)
 {
-    constexpr int NJ = BN / 64;                    // accumulator tiles per wave along N
-    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, BUF = A_BYTES + B_BYTES;
-    constexpr int BCH = BN * BK / 8 / NT;          // 16-B chunks of a B slab per lane
+    constexpr int NJ = GemmCfg<BN>::NJ;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -111,58 +226,6 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const bf16_t *__restri
     int id = blockIdx.x;
     if ((ntiles & 7) == 0) id = (id & 7) * (ntiles >> 3) + (id >> 3);       // XCD-aware: an XCD gets a run of tiles
     const int m0 = (id / tiles_n) * BM, n0 = (id % tiles_n) * BN;
-    const int nslab = (K + BK - 1) / BK;
-
-    uint4 ra[4], rb[BCH];
-    auto load_slab = [&](auto interior, int s) {
-        constexpr bool INTERIOR = decltype(interior)::value;
-        const int k0 = s * BK;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {                                        // A: 128 rows x 8 chunks
-            const int i = tid + NT * q, row = i >> 3, ch = i & 7;
-            const bf16_t *p = A + (size_t)(m0 + row) * lda + k0 + ch * 8;
-            if constexpr (INTERIOR) ra[q] = load8(p);
-            else {
-                const int nv = (m0 + row < M) ? min(8, max(0, K - (k0 + ch * 8))) : 0;
-                ra[q] = (vecA && nv == 8) ? load8(p) : load8_guard(p, nv);
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < BCH; ++q) {
-            const int i = tid + NT * q;
-            if constexpr (TB) {                                              // B [N][K]: BN rows x 8 chunks
-                const int row = i >> 3, ch = i & 7;
-                const TBm *p = Bm + (size_t)(n0 + row) * ldb + k0 + ch * 8;
-                if constexpr (INTERIOR) rb[q] = load8(p);
-                else {
-                    const int nv = (n0 + row < N) ? min(8, max(0, K - (k0 + ch * 8))) : 0;
-                    rb[q] = (vecB && nv == 8) ? load8(p) : load8_guard(p, nv);
-                }
-            } else {                                                         // B [K][N]: 64 k rows x BN/8 chunks
-                const int kr = i / (BN / 8), cc = i % (BN / 8);
-                const TBm *p = Bm + (size_t)(k0 + kr) * ldb + n0 + cc * 8;
-                if constexpr (INTERIOR) rb[q] = load8(p);
-                else {
-                    const int nv = (k0 + kr < K) ? min(8, max(0, N - (n0 + cc * 8))) : 0;
-                    rb[q] = (vecB && nv == 8) ? load8(p) : load8_guard(p, nv);
-                }
-            }
-        }
-    };
-    auto store_slab = [&](char *buf) {
-        char *As = buf, *Bs = buf + A_BYTES;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int i = tid + NT * q;
-            *reinterpret_cast<uint4 *>(As + kc_off(i >> 3, i & 7)) = ra[q];
-        }
-#pragma unroll
-        for (int q = 0; q < BCH; ++q) {
-            const int i = tid + NT * q;
-            if constexpr (TB) *reinterpret_cast<uint4 *>(Bs + kc_off(i >> 3, i & 7)) = rb[q];
-            else *reinterpret_cast<uint4 *>(Bs + km_off<BN>(i / (BN / 8), (i % (BN / 8)) * 8)) = rb[q];
-        }
-    };
 
     floatx16 acc[2][NJ];
 #pragma unroll
@@ -172,42 +235,10 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const bf16_t *__restri
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    auto multiply = [&](const char *buf) {
-        const char *As = buf, *Bs = buf + A_BYTES;
-#pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
-            bf16x8_t a[2], b[NJ];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-                a[i] = *reinterpret_cast<const bf16x8_t *>(As + kc_off(wm * 64 + i * 32 + r31, 2 * ks + half));
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                if constexpr (TB)
-                    b[j] = *reinterpret_cast<const bf16x8_t *>(Bs + kc_off(wn * (BN / 2) + j * 32 + r31, 2 * ks + half));
-                else
-                    b[j] = tr_frag<BN>(Bs, 16 * ks + 8 * half, wn * (BN / 2) + j * 32, lane);
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
-    };
-    auto main_loop = [&](auto interior) {
-        load_slab(interior, 0);
-        store_slab(smem);
-        __syncthreads();
-        for (int s = 0; s < nslab; ++s) {
-            char *cur = smem + (s & 1) * BUF, *nxt = smem + ((s + 1) & 1) * BUF;
-            if (s + 1 < nslab) load_slab(interior, s + 1);          // next slab's loads fly during the MFMAs
-            multiply(cur);
-            if (s + 1 < nslab) store_slab(nxt);
-            __syncthreads();
-        }
-    };
-    if (vecA && vecB && m0 + BM <= M && n0 + BN <= N && (K % BK) == 0) main_loop(std::true_type{});
-    else main_loop(std::false_type{});
+    if (vecA && vecB && m0 + BM <= M && n0 + BN <= N && (K % BK) == 0)
+        gemm_main_loop<true, TB, BN, TBm>(A, lda, Bm, ldb, m0, n0, M, N, K, vecA, vecB, smem, acc);
+    else
+        gemm_main_loop<false, TB, BN, TBm>(A, lda, Bm, ldb, m0, n0, M, N, K, vecA, vecB, smem, acc);
 
     // ---- epilogue: bias, BatchNorm tile statistics (from the fp32 accumulators), coalesced row stores
     float bv[NJ];
@@ -333,9 +364,10 @@ template <bool TB, typename TBm, bool OUT_F32>
 int dispatch_bn(const bf16_t *A, int lda, const TBm *B, int ldb, const float *bias, void *C, int ldc, int M, int N, int K,
                 float *stats, int vecA, int vecB, int vecC, hipStream_t st)
 {
-    // 128-column tiles halve the re-reads of A through L2; narrow outputs (and small grids) take 64
+    // 128-column tiles halve the re-reads of A through L2; narrow outputs, small grids and widths that 128 does
+    // not divide (a partial tile runs the element-wise edge loop) take 64
     const long long t128 = (long long)mpa_ceil_div(M, BM) * mpa_ceil_div(N, 128);
-    if (N > 64 && t128 >= 192)
+    if (N > 64 && t128 >= 192 && (N % 128 == 0 || N % 64 != 0))
         return launch_gemm_bf16<TB, 128, TBm, OUT_F32>(A, lda, B, ldb, bias, C, ldc, M, N, K, stats, vecA, vecB, vecC, st);
     return launch_gemm_bf16<TB, 64, TBm, OUT_F32>(A, lda, B, ldb, bias, C, ldc, M, N, K, stats, vecA, vecB, vecC, st);
 }

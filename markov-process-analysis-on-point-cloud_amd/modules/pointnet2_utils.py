@@ -416,10 +416,12 @@ class KeepHighResolutionModulePartSeg(nn.Module):
         d0 = self.la1_up(xyz=x0, base_xyz=x0, normal=n0, feature=self.up_conv1(upsample(d1, k1)))[0]
         d0 = self.fuse5(N, f0=d0, f1=e1, f2=e2, f3=e3, f4=e4, **geo)[0]
 
+        # per-cloud rows (five global maxima | label embedding) next to every point's conv5 features; the
+        # broadcast + concatenation is one op whose backward sums the per-cloud columns with this library's
+        # kernel (torch's expand() backward is a multi-workgroup reduction: see ops._CatBroadcast)
         glob = torch.cat([_max_over_points(t) for t in (d0, d1, d2, d3, d4)], dim=2)
-        glob = glob.expand(-1, N, -1)
-        lab = self.conv7(label.to(d0.dtype)).expand(-1, N, -1)          # (the one-hot joins the feature stream's dtype)
-        final = torch.cat((self.conv5(d0), glob, lab), 2)
+        lab = self.conv7(label.to(d0.dtype))                             # (the one-hot joins the feature stream's dtype)
+        final = ops.cat_broadcast(self.conv5(d0), torch.cat((glob, lab), 2))
         return x0, final
 
 

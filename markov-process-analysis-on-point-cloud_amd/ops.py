@@ -632,19 +632,48 @@ def three_interpolate(xyz1, xyz2, points2):
     return _ThreeInterp.apply(_f32(points2), idx, dist)
 
 
+class _CatBroadcast(torch.autograd.Function):
+    """cat((a [B,N,Ca], rows [B,1,Cr] broadcast over N), 2): per-point features next to per-cloud rows (the
+    part-seg head: conv5(points) | global maxima | label embedding, reference modules/pointnet2_utils.py:846-856).
+    Backward hands `a` its column block of the gradient in place and sums the broadcast columns per cloud with
+    mpa_group_col_sum -- not with torch's reduction, which autograd would pick for expand() and which returns
+    wrong values from the second replay of a captured HIP graph."""
+
+    @staticmethod
+    def forward(ctx, a, rows):
+        B, N, Ca = a.shape
+        Cr = rows.shape[2]
+        out = torch.empty(B, N, Ca + Cr, dtype=a.dtype, device=a.device)
+        out[:, :, :Ca] = a
+        out[:, :, Ca:] = rows
+        ctx.dims = (B, N, Ca, Cr)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, N, Ca, Cr = ctx.dims
+        g = g.contiguous()
+        grows = torch.empty(B, 1, Cr, dtype=torch.float32, device=g.device)
+        _launch("mpa_group_col_sum_" + _sfx(g), _vp(g.data_ptr() + g.element_size() * Ca), B, N, Cr, Ca + Cr, _p(grows),
+                _stream())
+        return g[:, :, :Ca], grows.to(g.dtype)
+
+
+def cat_broadcast(a, rows):
+    """torch.cat((a, rows.expand(-1, N, -1)), 2) for a [B,N,Ca] and per-cloud rows [B,1,Cr] (see _CatBroadcast)."""
+    _dev(a, rows)
+    return _CatBroadcast.apply(_feat(a), _feat(rows).to(a.dtype))
+
+
 # ------------------------------------------------------------------------------- transition MLP
-_WORKSPACES = {}
-
-
 def _workspace(device, nbytes):
-    """Persistent split-K scratch, one per (device, stream): kernels using it are ordered on that
-    stream, and a buffer that outlives the call is safe under HIP-graph capture and replay."""
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
-    ws = _WORKSPACES.get(key)
-    if ws is None or ws.numel() * 4 < nbytes:
-        ws = torch.empty(max(nbytes, 32 << 20) // 4, dtype=torch.float32, device=device)
-        _WORKSPACES[key] = ws
-    return ws
+    """Split-K scratch for one call: an ordinary temporary from torch's allocator.  Under HIP-graph capture it
+    comes from the graph's private pool and is recycled in stream order like every other temporary of the
+    step.  (Round 1 kept ONE persistent buffer per (device, stream) and replaced it when a call needed more:
+    replacing it in the middle of a capture freed memory whose address earlier nodes of the same graph had
+    baked in -- when that buffer came from an older, already released graph pool the replay wrote into
+    unmapped pages: "Memory access fault ... write access to a read-only page")"""
+    return torch.empty(max((nbytes + 3) // 4, 4), dtype=torch.float32, device=device)
 
 
 def _gemm(A, lda, tA, Bm, ldb, tB, bias, C, ldc, M, N, K, accumulate=0, tile_stats=None, a_col_sum=None):

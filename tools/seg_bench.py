@@ -1,6 +1,7 @@
 """Part-segmentation training step (ShapeNetPart-shaped: 2048 points, 16 object classes, 50 parts),
-fp32, HIP-graph replay -- SURVEY 8(d) config 3's shape at fp32 (development / secondary measurement).
-    python tools/seg_bench.py [batch] [steps]"""
+HIP-graph replay -- SURVEY 8(d) config 3's shape (development tool; the recorded number comes from
+`bench.py --config partseg-bf16`).
+    python tools/seg_bench.py [batch] [steps] [f32|bf16]"""
 import os
 import sys
 import time
@@ -15,6 +16,8 @@ from mpa_amd.runtime import GraphedTrainStep  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+DT = sys.argv[3] if len(sys.argv) > 3 else "f32"
+mpa_amd.ops.set_feature_dtype(torch.bfloat16 if DT == "bf16" else torch.float32)
 N = 2048
 dev = torch.device("cuda")
 g = torch.Generator().manual_seed(1234)
@@ -49,5 +52,5 @@ for _ in range(steps):
 torch.cuda.synchronize()
 print("losses:", " ".join("%.4f" % float(l) for l in losses[:: max(1, steps // 16)]), flush=True)
 dt = (time.perf_counter() - t0) / steps
-print("seg fp32 B=%d N=%d: %.2f ms/step, %.1f clouds/s, loss %.4f, peak mem %.1f GB" % (
-    B, N, dt * 1e3, B / dt, float(loss.detach()), torch.cuda.max_memory_allocated() / 2**30), flush=True)
+print("seg %s B=%d N=%d: %.2f ms/step, %.1f clouds/s, loss %.4f, peak mem %.1f GB" % (
+    DT, B, N, dt * 1e3, B / dt, float(loss.detach()), torch.cuda.max_memory_allocated() / 2**30), flush=True)
