@@ -1,23 +1,29 @@
-"""bench.py -- point-clouds/sec, forward+backward, ModelNet40-shaped 1024-point classification
-(BASELINE.json metric) on N MI355X GPUs of one node.
+"""bench.py -- point-clouds/sec, forward+backward, on N MI355X GPUs of one node.
 
-A "step" is one training pass of the hot path over one batch of synthetic clouds:
-forward (FPS -> kNN grouping -> difference-wise attention -> transition MLPs -> head), the
-label-smoothed loss, backward, gradient all-reduce over RCCL when N > 1, and an Adam step.
-Workload at N=1: BASELINE configs[1] -- 1024 points, batch 64 per GPU, fp32 (weak scaling:
-per-GPU batch fixed).  Inputs are resident in HBM before the timed region.
+A "step" is one training pass of the hot path over one batch of synthetic clouds: forward (FPS -> kNN
+grouping -> difference-wise attention -> transition MLPs -> head / decoder), the label-smoothed loss,
+backward, gradient all-reduce over RCCL when N > 1, and an Adam step.  Inputs are resident in HBM before
+the timed region; weak scaling (per-GPU batch fixed).
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 1 --steps 20 --warmup 5                       # default: BASELINE configs[1]
+    python bench.py --config partseg-bf16                                # BASELINE configs[2]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line.  Extra objects: "roofline" for the dominant kernel (HIP events on
-the launch stream around that kernel's launches inside the timed region), "cpu_baseline" (the
-CPU oracle oracle/ref_cpu.py timed on this box's host cores on a bounded sample; rank 0, N=1;
-its "forward_only_value" is the same model's forward pass alone) and, at N=1, "forward_only" (the
-forward pass alone as a HIP graph, measured after the timed region: a secondary figure).
+--config   cls-fp32      ModelNet40-shaped classification, 1024 points, batch 64/GPU, fp32   (BASELINE configs[1]; default,
+                         the configuration BASELINE.json's metric is quoted on)
+           cls-bf16      the same model on bf16 features
+           partseg-fp32  ShapeNetPart-shaped part segmentation, 2048 points, batch 32/GPU, fp32
+           partseg-bf16  the same on bf16 features                                            (BASELINE configs[2])
+
+Rank 0 prints ONE JSON line.  Extra objects: "roofline" for the dominant kernel (HIP events on the launch
+stream around that kernel's launches), "cpu_baseline" (the CPU oracle oracle/ref_cpu.py timed on this box's
+host cores on a bounded sample; rank 0, N=1, cls configs) and, at N=1, "forward_only" (the forward pass alone
+as a HIP graph, measured after the timed region: a secondary figure).
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
 import sys
@@ -28,24 +34,45 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-NUM_POINT, NUM_CLASS = 1024, 40
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 MFMA_F32_PEAK_TFLOPS = 157.3     # dense fp32 MFMA peak (MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32)
-# kernels timed with HIP events for the roofline leg: name -> bound
-# (mpa_gemm_f32 launches are priced by the device kernel they pick: the 64x64-tile kernel against the
-#  MFMA peak, the short-K kernel of the K <= 128 layers -- 16 FLOP/B -- against HBM)
-TIMED = {"mpa_gemm_f32/tiled": "mfma", "mpa_gemm_f32/shortk": "hbm", "mpa_gemm_tn_grouped_f32": "mfma",
-         "mpa_knn_f32": "mfma", "mpa_diffattn_fwd_f32": "hbm", "mpa_diffattn_bwd_f32": "hbm"}
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak (MI355X_MICROARCH.md; the 5 PF figure is 2:1 sparse)
+
+CONFIGS = {
+    # name: (task, dtype, points, default batch, BASELINE.json config)
+    "cls-fp32": ("cls", "f32", 1024, 64, "BASELINE configs[1]"),
+    "cls-bf16": ("cls", "bf16", 1024, 64, "configs[1]'s model on bf16 features"),
+    "partseg-fp32": ("partseg", "f32", 2048, 32, "configs[2]'s model at fp32"),
+    "partseg-bf16": ("partseg", "bf16", 2048, 32, "BASELINE configs[2]"),
+}
+# kernels timed with HIP events for the roofline leg: name -> bound.  fp32: the 64x64-tile GEMM is priced
+# against the fp32 MFMA peak, the short-K kernel (K <= 128 layers, 16 FLOP/B) against HBM.  bf16: every
+# product of the path is below the machine balance (32..200 FLOP/B against ~310), so all are priced on HBM.
+TIMED = {
+    "f32": {"mpa_gemm_f32/tiled": "mfma", "mpa_gemm_f32/shortk": "hbm", "mpa_gemm_tn_grouped_f32": "mfma",
+            "mpa_knn_f32": "mfma", "mpa_diffattn_fwd_f32": "hbm", "mpa_diffattn_bwd_f32": "hbm"},
+    "bf16": {"mpa_gemm_bf16": "hbm", "mpa_gemm_tn_grouped_bf16": "hbm", "mpa_knn_f32": "mfma",
+             "mpa_diffattn_fwd_bf16": "hbm", "mpa_diffattn_bwd_bf16": "hbm"},
+}
+NUM_CLASS, NUM_PART, NUM_OBJ = 40, 50, 16
 
 
-def synthetic_batch(B, seed, device):
-    """uniform(-1,1) clouds, centred and scaled into the unit sphere; random labels."""
-    g = torch.Generator().manual_seed(seed)
-    x = torch.rand(B, NUM_POINT, 3, generator=g) * 2 - 1
+def unit_clouds(B, N, g):
+    """uniform(-1,1) clouds, centred and scaled into the unit sphere."""
+    x = torch.rand(B, N, 3, generator=g) * 2 - 1
     x = x - x.mean(1, keepdim=True)
-    x = x / x.norm(dim=-1).max(dim=1)[0].view(B, 1, 1)
-    y = torch.randint(0, NUM_CLASS, (B,), generator=g)
-    return x.transpose(1, 2).contiguous().to(device), y.to(device)
+    return (x / x.norm(dim=-1).max(dim=1)[0].view(B, 1, 1)).transpose(1, 2).contiguous()
+
+
+def synthetic_batch(task, B, N, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    x = unit_clouds(B, N, g)
+    if task == "cls":
+        return (x.to(device), torch.randint(0, NUM_CLASS, (B,), generator=g).to(device))
+    label = torch.zeros(B, 1, NUM_OBJ)
+    label[torch.arange(B), 0, torch.randint(0, NUM_OBJ, (B,), generator=g)] = 1
+    target = torch.randint(0, NUM_PART, (B, N), generator=g)
+    return (x.to(device), label.to(device), target.to(device))
 
 
 def host_cores():
@@ -73,24 +100,42 @@ def log(msg):
     print("[bench] " + msg, file=sys.stderr, flush=True)
 
 
-def forward_only(model, x, feeder, iters=50):
+def kernel_sources_sha():
+    """sha256 (16 hex digits) over the kernel sources: ties an offline PMC profile to the code it measured."""
+    h = hashlib.sha256()
+    for path in sorted(glob.glob(os.path.join(ROOT, "markov-process-analysis-on-point-cloud_amd", "csrc", "*.h*"))):
+        h.update(os.path.basename(path).encode())
+        h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def forward_only(run_forward, feeder, arena, batch, iters=50):
     """Forward pass alone (train-mode BatchNorm statistics, no autograd), captured as a HIP graph: a
     secondary figure next to the headline fwd+bwd metric (SURVEY 8d states the >= 20x target on it)."""
+    from mpa_amd import ops
+
+    def one_pass():
+        feeder.begin_pass()
+        arena.begin()
+        ops.set_arena(arena)
+        try:
+            run_forward()
+        finally:
+            ops.set_arena(None)
+            arena.end()
+            feeder.end_pass()
+
     with torch.no_grad():
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(2):
-                feeder.begin_pass()
-                model(x)
-                feeder.end_pass()
+                one_pass()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            feeder.begin_pass()
-            model(x)
-            feeder.end_pass()
+            one_pass()
         for _ in range(5):
             feeder.refill()
             g.replay()
@@ -101,25 +146,36 @@ def forward_only(model, x, feeder, iters=50):
             g.replay()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / iters
-    return {"value": x.shape[0] / dt, "unit": "point-clouds/s", "ms_per_step": dt * 1e3, "steps": iters}
+    return {"value": batch / dt, "unit": "point-clouds/s", "ms_per_step": dt * 1e3, "steps": iters}
 
 
-def cpu_baseline(batch, steps=3):
-    """The oracle's plain-PyTorch restatement of the reference path, fwd+bwd+Adam on host cores."""
+def cpu_baseline(task, batch, npoint, steps=3):
+    """The oracle's plain-PyTorch restatement of the reference path, fwd+bwd+Adam on host cores (fp32: the
+    reference has no reduced-precision mode)."""
     from oracle import ref_cpu as R
     threads = int(os.environ.get("MPA_CPU_THREADS", host_cores()))
     log("cpu baseline on %d threads (os.cpu_count()=%s)" % (threads, os.cpu_count()))
     torch.set_num_threads(threads)
     torch.manual_seed(0)
-    args = argparse.Namespace(num_point=NUM_POINT, return_dist=True, cuda_ops=False, num_class=NUM_CLASS)
-    model = R.ClsModel(args).train()
+    if task == "cls":
+        args = argparse.Namespace(num_point=npoint, return_dist=True, cuda_ops=False, num_class=NUM_CLASS)
+        model = R.ClsModel(args).train()
+        x, y = synthetic_batch(task, batch, npoint, 1234, "cpu")
+        fwd = lambda: model(x)                                   # noqa: E731
+        loss_of = lambda out: R.smooth_cls_loss(out, y)          # noqa: E731
+        name = "ClsModel"
+    else:
+        model = R.PartSegModel(NUM_PART).train()
+        x, lab, tgt = synthetic_batch(task, batch, npoint, 1234, "cpu")
+        fwd = lambda: model(x, lab)[0]                           # noqa: E731
+        loss_of = lambda out: R.partseg_loss(out.reshape(-1, NUM_PART), tgt.reshape(-1))        # noqa: E731
+        name = "PartSegModel"
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
-    x, y = synthetic_batch(batch, 1234, "cpu")
     times = []
     for i in range(steps + 1):
         t0 = time.perf_counter()
         opt.zero_grad(set_to_none=True)
-        loss = R.smooth_cls_loss(model(x), y)
+        loss = loss_of(fwd())
         loss.backward()
         opt.step()
         times.append(time.perf_counter() - t0)
@@ -130,13 +186,13 @@ def cpu_baseline(batch, steps=3):
     with torch.no_grad():                                  # forward only (the >= 20x target is on forward)
         for i in range(steps + 1):
             t0 = time.perf_counter()
-            model(x)
+            fwd()
             ftimes.append(time.perf_counter() - t0)
     fmed = sorted(ftimes[1:])[len(ftimes[1:]) // 2]
     log("cpu baseline forward only: %.2f s" % fmed)
     return {"value": batch / med, "unit": "point-clouds/s", "cores": threads, "kind": "port",
-            "sample": "oracle/ref_cpu.py ClsModel fwd+bwd+Adam, batch %d x %d pts, 1 warm-up + %d timed steps, median"
-                      % (batch, NUM_POINT, steps),
+            "sample": "oracle/ref_cpu.py %s fp32 fwd+bwd+Adam, batch %d x %d pts, 1 warm-up + %d timed steps, median"
+                      % (name, batch, npoint, steps),
             "forward_only_value": batch / fmed}
 
 
@@ -145,10 +201,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=64, help="clouds per GPU")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="cls-fp32")
+    ap.add_argument("--batch", type=int, default=0, help="clouds per GPU (default: the configuration's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python (no HIP graph)")
     a = ap.parse_args()
+    task, dt, npoint, dbatch, which = CONFIGS[a.config]
+    batch = a.batch or dbatch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -162,15 +221,38 @@ def main():
     import mpa_amd  # noqa: F401
     from mpa_amd import ops
     from mpa_amd import distributed as mdist
-    from mpa_amd.models.repsurf.repsurf_ssg_umb import Model, SmoothClsLoss
 
     if world > 1:
         mdist.init_process_group(os.environ.get("MPA_DIST_BACKEND"))
+    ops.set_feature_dtype(torch.bfloat16 if dt == "bf16" else torch.float32)
     torch.manual_seed(0)
-    args = argparse.Namespace(num_point=NUM_POINT, return_dist=True, cuda_ops=True, num_class=NUM_CLASS)
-    model = Model(args).to(dev).train()
-    crit = SmoothClsLoss()
-    x, y = synthetic_batch(a.batch, 1234 + rank, dev)
+    data = synthetic_batch(task, batch, npoint, 1234 + rank, dev)
+    if task == "cls":
+        from mpa_amd.models.repsurf.repsurf_ssg_umb import Model, SmoothClsLoss
+        args = argparse.Namespace(num_point=npoint, return_dist=True, cuda_ops=True, num_class=NUM_CLASS)
+        model = Model(args).to(dev).train()
+        crit = SmoothClsLoss()
+        compute_loss = None
+        run_forward = lambda: model(data[0])                     # noqa: E731
+        loss_eager = lambda: crit(model(data[0]), data[1])       # noqa: E731
+        metric = "point-clouds/sec fwd+bwd, ModelNet40 1024pt cls"
+        workload = "ModelNet40-shaped classification, %d points, batch %d per GPU" % (npoint, batch)
+    else:
+        from mpa_amd.models.repsurf.pointnet2_part_seg_msg import get_model, get_loss
+        model = get_model(NUM_PART).to(dev).train()
+        crit = get_loss()
+
+        def compute_loss(model, crit, x, label, target):
+            pred, _ = model(x, label)
+            return crit(pred.reshape(-1, NUM_PART), target.reshape(-1))
+
+        run_forward = lambda: model(data[0], data[1])            # noqa: E731
+        loss_eager = lambda: compute_loss(model, crit, *data)    # noqa: E731
+        metric = "point-clouds/sec fwd+bwd, ShapeNetPart 2048pt part-seg"
+        workload = "ShapeNetPart-shaped part segmentation, %d points, batch %d per GPU" % (npoint, batch)
+    workload += ", %s%s, fwd+loss+bwd+Adam (%s)" % ("fp32" if dt == "f32" else "bf16 features / fp32 accumulate, statistics, "
+                                                   "coordinates and parameters", "", which)
+
     if a.eager:
         reducer = mdist.GradReducer(model) if world > 1 else None
         opt = torch.optim.Adam(model.parameters(), lr=1e-3)
@@ -180,7 +262,7 @@ def main():
                 reducer.zero_grad()
             else:
                 opt.zero_grad(set_to_none=True)
-            loss = crit(model(x), y)
+            loss = loss_eager()
             loss.backward()
             if reducer is not None:
                 reducer.all_reduce()
@@ -189,17 +271,18 @@ def main():
     else:
         # the whole forward+backward is one HIP graph; all-reduce + (graphed) Adam follow it
         from mpa_amd.runtime import GraphedTrainStep
-        graphed = GraphedTrainStep(model, crit, (x, y), lr=1e-3)      # optim.FlatAdam on the flat buckets
+        graphed = GraphedTrainStep(model, crit, data, lr=1e-3, compute_loss=compute_loss)   # optim.FlatAdam on flat buckets
 
         def step():
-            return graphed(x, y)
+            return graphed(*data)
 
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize()
     log("rank %d: warm-up done" % rank)
+    timed = TIMED[dt]
     if a.eager:
-        ops.enable_kernel_timing(list(TIMED))
+        ops.enable_kernel_timing(list(timed))
     mdist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -215,7 +298,7 @@ def main():
         # A replayed HIP graph has no per-kernel event hooks: the kernels are timed live, with HIP
         # events on their launch stream, in an eagerly launched pass over the same step right
         # after the timed region (same shapes, same data).
-        ops.enable_kernel_timing(list(TIMED))
+        ops.enable_kernel_timing(list(timed))
         for _ in range(min(a.steps, 10)):
             graphed._fwd_bwd()
     kt = ops.kernel_timing_results()
@@ -230,15 +313,28 @@ def main():
         pair_us = sorted(e0.elapsed_time(e1) * 1e3 for e0, e1 in evs)[50]
 
     if rank == 0:
-        clouds = a.batch * world * a.steps
-        traffic = {}
-        try:        # HBM bytes per launch from the committed rocprofv3 PMC passes (see the file's "how")
-            with open(os.path.join(ROOT, "profiles", "r01f_pmc_traffic.json")) as fh:
-                traffic = {k: v.get("hbm_bytes_per_launch") for k, v in json.load(fh)["kernels"].items()}
-        except (OSError, ValueError, KeyError):
-            pass
+        clouds = batch * world * a.steps
+        # HBM bytes per launch come from committed rocprofv3 PMC passes (collected offline exactly as
+        # MI355X_MICROARCH.md prescribes: separate --pmc FETCH_SIZE / WRITE_SIZE runs).  The file records the
+        # sha of the kernel sources it measured; if the sources have changed since, traffic is reported as null.
+        traffic, traffic_source = {}, None
+        src_sha = kernel_sources_sha()
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_pmc_traffic.json" % a.config.replace("-", "_"))))
+        if cands:
+            try:
+                with open(cands[-1]) as fh:
+                    pmc = json.load(fh)
+                fresh = pmc.get("kernel_sources_sha") == src_sha
+                traffic_source = "%s (offline rocprofv3 --pmc passes; kernel sources %s: %s)" % (
+                    os.path.relpath(cands[-1], ROOT), pmc.get("kernel_sources_sha"),
+                    "current" if fresh else "STALE, sources are now %s -> traffic withheld" % src_sha)
+                if fresh:
+                    traffic = {k: v.get("hbm_bytes_per_launch") for k, v in pmc["kernels"].items()}
+            except (OSError, ValueError, KeyError):
+                pass
+        peak_mfma = MFMA_F32_PEAK_TFLOPS if dt == "f32" else MFMA_BF16_PEAK_TFLOPS
         kernels = []
-        for name, bound in TIMED.items():
+        for name, bound in timed.items():
             r = kt.get(name)
             if not r or not r["launches"]:
                 continue
@@ -246,7 +342,8 @@ def main():
             if bound == "hbm":
                 ach, peak, unit = r["algo_bytes"] / sec / 1e9, HBM_PEAK_GBS, "GB/s"
             else:
-                ach, peak, unit = r["algo_flops"] / sec / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
+                pk = MFMA_F32_PEAK_TFLOPS if name.endswith("_f32") or "_f32/" in name else peak_mfma
+                ach, peak, unit = r["algo_flops"] / sec / 1e12, pk, "TFLOP/s"
             kernels.append({"kernel": name, "bound": bound, "achieved": ach, "peak": peak, "unit": unit,
                             "frac": ach / peak, "traffic": traffic.get(name), "launches": r["launches"],
                             "avg_launch_us": r["ms"] * 1e3 / r["launches"], "total_ms": r["ms"],
@@ -255,26 +352,27 @@ def main():
         kernels.sort(key=lambda k: -k["total_ms"])
         roof = dict(kernels[0]) if kernels else None       # the dominant kernel by measured time
         if roof:
+            roof["traffic_source"] = traffic_source
             roof["empty_event_pair_us"] = pair_us     # included in avg_launch_us (not subtracted): frac is a lower bound
             roof["measured"] = ("HIP events around every launch of the kernel, " +
                                 ("inside the timed region" if a.eager else
                                  "eager pass over the same step right after the timed (graph-replayed) region"))
         line = {
-            "metric": "point-clouds/sec fwd+bwd, ModelNet40 1024pt cls", "value": clouds / elapsed,
+            "metric": metric, "value": clouds / elapsed,
             "unit": "point-clouds/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "ModelNet40-shaped classification, 1024 points, batch %d per GPU, fp32, "
-                                   "fwd+loss+bwd+Adam (BASELINE configs[1])" % a.batch,
-                       "points": NUM_POINT, "batch_per_gpu": a.batch, "global_batch": a.batch * world,
-                       "parallelism": "dp%d" % world, "launch": "eager" if a.eager else "hipgraph"},
+            "vs_baseline": None, "dtype": dt, "data": "synthetic",
+            "config": {"workload": workload, "name": a.config, "points": npoint, "batch_per_gpu": batch,
+                       "global_batch": batch * world, "parallelism": "dp%d" % world,
+                       "launch": "eager" if a.eager else "hipgraph"},
             "roofline": roof,
             "roofline_other_kernels": kernels[1:],
         }
         if world == 1 and not a.eager:
-            line["forward_only"] = forward_only(model, x, graphed.feeder)
+            line["forward_only"] = forward_only(run_forward, graphed.feeder, graphed.arena, batch)
         if world == 1 and not a.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(a.batch)
+            line["cpu_baseline"] = cpu_baseline(task, batch if task == "cls" else min(batch, 4), npoint,
+                                                steps=3 if task == "cls" else 2)
         print(json.dumps(line), flush=True)
     mdist.shutdown()
 

@@ -150,6 +150,11 @@ int mpa_diffattn_xyz_bwd_f32(const float *xyz, const float *center, const int64_
  *   64-row tile and column the sum and the sum of squared deviations from the tile mean -- the
  *   BatchNorm batch statistics in Chan's pairwise form (no atomics: deterministic; no
  *   E[y^2]-E[y]^2 cancellation).  mpa_bn_finalize_f32 combines them.
+ *   stats_replicas = R > 0 selects the ACCUMULATE form instead: tile_stats is [R][3][N] floats, pre-zeroed by the
+ *   caller, and every 64-row tile adds (float atomics, replica = tile index mod R) its sum, its within-tile M2 and
+ *   sum^2/rows per column; mpa_bn_stats_act_fwd_f32 finishes mean / variance from them in its own prologue, so
+ *   the Linear unit needs no separate finalize launch (the between-tile part of the variance is then taken from
+ *   the tile sums: exact within tiles, ~1e-7 * mean^2/var relative between them).
  *   a_col_sum (optional, [M], cleared by the caller): receives sum_k op(A)[m][k] with float atomics
  *   -- the bias gradient, for free, when op(A) = dY^T in the weight-gradient product.
  *   workspace (optional, 16-B aligned): scratch for split-K partial tiles (weight gradients have
@@ -157,7 +162,8 @@ int mpa_diffattn_xyz_bwd_f32(const float *xyz, const float *center, const int64_
  *   accumulate != 0 adds into C. */
 int mpa_gemm_f32(const float *A, int lda, int transA, const float *B, int ldb, int transB,
                  const float *bias, float *C, int ldc, int M, int N, int K, int accumulate,
-                 float *tile_stats, float *a_col_sum, float *workspace, size_t workspace_bytes, void *stream);
+                 float *tile_stats, int stats_replicas, float *a_col_sum, float *workspace, size_t workspace_bytes,
+                 void *stream);
 /* Grouped weight gradients: out_p[M,N] = A_p^T B_p for `count` independent problems in one launch
  * (+ one reduce launch), A_p stored [K][M] (lda), B_p stored [K][N] (ldb): dW = dY^T X of every
  * Linear of a backward pass.  Each is a latency-bound stream with a tiny output, so they are
@@ -191,6 +197,14 @@ int mpa_bn_finalize_f32(const float *tile_stats, int M, int C, float *running_me
  * modules/pointnet2_utils.py:572, fused into the same pass).  In place allowed (y == x). */
 int mpa_bn_act_fwd_f32(const float *x, const float *save_mean_invstd, const float *gamma, const float *beta,
                        const float *residual, float slope, int M, int C, float *y, void *stream);
+/* The same with the statistics finished inside the launch from the accumulate form of the GEMM epilogue
+ * (stats [replicas][3][C], see mpa_gemm_f32): every workgroup derives mean / 1/sqrt(var+eps) in its prologue,
+ * workgroup 0 also stores them to save_mean_invstd [2][C] (for the backward pass) and updates running_mean /
+ * running_var / num_batches_tracked as nn.BatchNorm1d does.  training == 0: running statistics (stats unused). */
+int mpa_bn_stats_act_fwd_f32(const float *x, const float *stats, int replicas, int M, int C,
+                             float *running_mean, float *running_var, int training, float momentum, float eps,
+                             int64_t *num_batches_tracked, const float *gamma, const float *beta,
+                             const float *residual, float slope, float *y, float *save_mean_invstd, void *stream);
 /* out[c] += sum over the M rows of x[r*ld + c]  (bias gradients; out [C] cleared by the caller). */
 int mpa_col_sum_f32(const float *x, int M, int C, int ld, float *out, void *stream);
 /* out[g][c] = sum over the R rows of group g of x[(g*R + r)*ld + c], x [G*R, >= C] (leading dimension ld), out [G,C]
@@ -284,7 +298,7 @@ int mpa_adam_step_f32(float *param, const float *grad, float *exp_avg, float *ex
  * 16-byte aligned take an element-wise path. */
 int mpa_gemm_bf16(const mpa_bf16 *A, int lda, const void *B, int ldb, int transB, int b_is_f32,
                   const float *bias, void *C, int ldc, int c_is_f32, int M, int N, int K,
-                  float *tile_stats, void *stream);
+                  float *tile_stats, int stats_replicas, void *stream);
 /* Grouped weight gradients on bf16 operands: out_p[M,N] (fp32) = A_p^T B_p, A_p [K][M] (lda), B_p [K][N] (ldb)
  * bf16 -- dW = dY^T X of every Linear of a backward pass in one launch (+ one reduce launch); same contract
  * as mpa_gemm_tn_grouped_f32 (a_col_sum optional, fp32, cleared by the caller; problems is a HOST array). */
@@ -301,6 +315,11 @@ int mpa_gemm_tn_grouped_bf16(const MpaGemmTnProblemBf16 *problems, int count, fl
  * (mpa_bn_finalize_f32 is shared).  Same semantics as the _f32 entry points. */
 int mpa_bn_act_fwd_bf16(const mpa_bf16 *x, const float *save_mean_invstd, const float *gamma, const float *beta,
                         const mpa_bf16 *residual, float slope, int M, int C, mpa_bf16 *y, void *stream);
+int mpa_bn_stats_act_fwd_bf16(const mpa_bf16 *x, const float *stats, int replicas, int M, int C,
+                              float *running_mean, float *running_var, int training, float momentum, float eps,
+                              int64_t *num_batches_tracked, const float *gamma, const float *beta,
+                              const mpa_bf16 *residual, float slope, mpa_bf16 *y, float *save_mean_invstd,
+                              void *stream);
 int mpa_bn_act_bwd_reduce_bf16(const mpa_bf16 *x, const mpa_bf16 *grad_y, const float *mean, const float *invstd,
                                const float *gamma, const float *beta, float slope, int M, int C,
                                int ldg, float *partial, int replicas, void *stream);

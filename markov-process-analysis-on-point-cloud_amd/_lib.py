@@ -41,7 +41,8 @@ SIGNATURES = {
     "mpa_diffattn_bwd_workspace_bytes": [_i, _i, _i, _i, _i],
     "mpa_diffattn_xyz_fwd_f32": [_vp] * 9 + [_i] * 5 + [_vp, _vp, _vp],
     "mpa_diffattn_xyz_bwd_f32": [_vp] * 11 + [_i] * 5 + [_vp] * 6 + [_vp],
-    "mpa_gemm_f32": [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, ctypes.c_size_t, _vp],
+    "mpa_gemm_f32": [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, ctypes.c_size_t, _vp],
+    "mpa_bn_stats_act_fwd_f32": [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _f, _f, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp],
     "mpa_tile_stats_f32": [_vp, _i, _i, _vp, _vp],
     "mpa_bn_finalize_f32": [_vp, _i, _i, _vp, _vp, _i, _f, _f, _vp, _vp, _i, _vp, _vp],
     "mpa_col_stats_f32": [_vp, _i, _i, _vp, _vp, _vp],
@@ -76,7 +77,8 @@ class GemmTnProblemBf16(ctypes.Structure):
 
 # ---- bf16 feature path (same argument order as the _f32 entry points unless noted)
 SIGNATURES.update({
-    "mpa_gemm_bf16": [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
+    "mpa_gemm_bf16": [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp],
+    "mpa_bn_stats_act_fwd_bf16": SIGNATURES["mpa_bn_stats_act_fwd_f32"],
     "mpa_gemm_tn_grouped_bf16": [ctypes.POINTER(GemmTnProblemBf16), _i, _vp, ctypes.c_size_t, _vp],
     "mpa_bn_act_fwd_bf16": SIGNATURES["mpa_bn_act_fwd_f32"],
     "mpa_bn_act_bwd_reduce_bf16": SIGNATURES["mpa_bn_act_bwd_reduce_f32"],

@@ -7,7 +7,7 @@
 
 namespace {
 
-constexpr int CSR_MAX_N = 12288;       // 2N ints of LDS <= 96 KB for a single row range
+constexpr int CSR_MAX_N = 65536;       // rows per cloud; a workgroup's row range is <= max(256, N/64): <= 8 KB of LDS
 
 // One workgroup per (cloud, range of base rows): it scans all S*K entries of the cloud, counts
 // those of its rows in LDS (integer LDS atomics are as slow as the float ones, so the rows are
@@ -102,10 +102,6 @@ inline void launch_csr_build(const int64_t *idx, int B, int N, int SK, int *rowp
     int ranges = 1;                                       // workgroups per cloud: ~256 rows each, >= 256 in all
     while (ranges < 64 && (N / ranges > 256 || B * ranges < 256) && N / (2 * ranges) >= 32) ranges <<= 1;
     const int range = (N + ranges - 1) / ranges;
-    static int attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&csr_build_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          2 * CSR_MAX_N * (int)sizeof(int));
-    (void)attr;
     hipLaunchKernelGGL(csr_build_kernel, dim3(mpa_ceil_div(N, range), B), dim3(CSR_TPB),
                        (size_t)2 * range * sizeof(int), st, idx, N, SK, range, rowptr, entries);
 }

@@ -40,7 +40,8 @@ __device__ __forceinline__ void gemm_body(const int block_x, const int block_z, 
                                           const float *__restrict__ B, int ldb, const float *__restrict__ bias,
                                           float *__restrict__ C, int ldc, int M, int N, int K, int kchunk,
                                           int out_mode, int vecA, int vecB, float *__restrict__ tile_stats,
-                                          float *__restrict__ zero_c, float *__restrict__ a_col_sum, int tn_stream)
+                                          float *__restrict__ zero_c, float *__restrict__ a_col_sum, int tn_stream,
+                                          int stats_acc = 0)
 {
     // out_mode 0: C = result (+bias);  1: atomicAdd into C;  2: split-K partial slab
     //             C + blockIdx.z*M*ldc (plain stores, summed by splitk_reduce_kernel).
@@ -426,9 +427,17 @@ __device__ __forceinline__ void gemm_body(const int block_x, const int block_z, 
         __syncthreads();
         if (tid < TS && n0 + tid < N) {
             const float m2 = (st[5 * TS + tid] + st[6 * TS + tid]) + (st[7 * TS + tid] + st[8 * TS + tid]);
-            float *dst = tile_stats + (size_t)tile_m * 2 * N + n0 + tid;
-            dst[0] = tsum;
-            dst[N] = m2;
+            if (stats_acc > 0) {
+                // accumulate form [R][3][N]: sum, within-tile M2, sum^2/rows -- mpa_bn_stats_act_fwd finishes them
+                float *dst = tile_stats + (size_t)(tile_m % stats_acc) * 3 * N + n0 + tid;
+                atomicAdd(dst, tsum);
+                atomicAdd(dst + N, m2);
+                atomicAdd(dst + 2 * N, tsum * tsum / (float)nrows);
+            } else {
+                float *dst = tile_stats + (size_t)tile_m * 2 * N + n0 + tid;
+                dst[0] = tsum;
+                dst[N] = m2;
+            }
         }
     }
 }
@@ -439,10 +448,10 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const float *__restrict__ A
                                                      const float *__restrict__ bias, float *__restrict__ C, int ldc,
                                                      int M, int N, int K, int kchunk, int out_mode, int vecA,
                                                      int vecB, float *__restrict__ tile_stats, float *__restrict__ zero_c,
-                                                     float *__restrict__ a_col_sum, int tn_stream)
+                                                     float *__restrict__ a_col_sum, int tn_stream, int stats_acc)
 {
     gemm_body<TA, TB>(blockIdx.x, blockIdx.z, A, lda, B, ldb, bias, C, ldc, M, N, K, kchunk, out_mode, vecA, vecB,
-                      tile_stats, zero_c, a_col_sum, tn_stream);
+                      tile_stats, zero_c, a_col_sum, tn_stream, stats_acc);
 }
 
 // ---- grouped weight-gradient products: many independent small  out_p[M_p,N_p] = A_p^T B_p  (A_p, B_p
@@ -493,7 +502,8 @@ template <bool TB, int NS>
 __global__ __launch_bounds__(NT, 4) void gemm_shortk_kernel(const float *__restrict__ A, int lda,
                                                             const float *__restrict__ B, int ldb,
                                                             const float *__restrict__ bias, float *__restrict__ C,
-                                                            int ldc, int M, int N, float *__restrict__ tile_stats)
+                                                            int ldc, int M, int N, float *__restrict__ tile_stats,
+                                                            int stats_acc)
 {
     constexpr int LDA = TS, LDB = TS;
     constexpr int BUF = KS * (LDA + LDB);
@@ -581,9 +591,17 @@ __global__ __launch_bounds__(NT, 4) void gemm_shortk_kernel(const float *__restr
         if (half == 0) st[128 + wave * 32 + l31] = m2;
         __syncthreads();
         if (mq == 0 && half == 0) {
-            float *dst = tile_stats + (size_t)tile_m * 2 * N + col;
-            dst[0] = tsum;
-            dst[N] = st[128 + wave * 32 + l31] + st[128 + (wave ^ 1) * 32 + l31];
+            const float m2t = st[128 + wave * 32 + l31] + st[128 + (wave ^ 1) * 32 + l31];
+            if (stats_acc > 0) {
+                float *dst = tile_stats + (size_t)(tile_m % stats_acc) * 3 * N + col;
+                atomicAdd(dst, tsum);
+                atomicAdd(dst + N, m2t);
+                atomicAdd(dst + 2 * N, tsum * tsum * (1.0f / TS));
+            } else {
+                float *dst = tile_stats + (size_t)tile_m * 2 * N + col;
+                dst[0] = tsum;
+                dst[N] = m2t;
+            }
         }
     }
 }
@@ -593,14 +611,14 @@ constexpr size_t gemm_lds_bytes(bool, bool) { return sizeof(float) * 2 * KS * (T
 template <bool TA, bool TB>
 int launch_gemm(const float *A, int lda, const float *B, int ldb, const float *bias, float *C, int ldc, int M, int N,
                 int K, int splits, int kchunk, int out_mode, int vecA, int vecB, float *stats, float *zero_c,
-                float *a_col_sum, hipStream_t st)
+                float *a_col_sum, int stats_acc, hipStream_t st)
 {
     static const int tn_stream = getenv("MPA_TN_STREAM") ? atoi(getenv("MPA_TN_STREAM")) : 1;
     constexpr size_t lds = gemm_lds_bytes(TA, TB);
     static_assert(lds >= sizeof(float) * 4 * TS * TS && lds <= 64 * 1024, "reduction region fits, no opt-in");
     dim3 grid(mpa_ceil_div(M, TS) * mpa_ceil_div(N, TS), 1, splits);
     hipLaunchKernelGGL((gemm_kernel<TA, TB>), grid, dim3(NT), lds, st, A, lda, B, ldb, bias, C, ldc, M, N, K, kchunk,
-                       out_mode, vecA, vecB, stats, zero_c, a_col_sum, tn_stream);
+                       out_mode, vecA, vecB, stats, zero_c, a_col_sum, tn_stream, stats_acc);
     return MPA_OK;
 }
 
@@ -633,7 +651,7 @@ constexpr int EW_TPB = 256;
 // Per-tile statistics of an existing [M,C] tensor in the GEMM epilogue's format
 // (tile_stats [ceil(M/64)][2][C]: sum, sum of squared deviations from the tile mean).
 __global__ __launch_bounds__(256) void tile_stats_kernel(const float *__restrict__ x, int M, int C,
-                                                         float *__restrict__ tile_stats)
+                                                         float *__restrict__ tile_stats, int stats_acc)
 {
     __shared__ float red[4][64];
     __shared__ float mean[64];
@@ -664,9 +682,17 @@ __global__ __launch_bounds__(256) void tile_stats_kernel(const float *__restrict
     red[g][cl] = m2;
     __syncthreads();
     if (g == 0 && c < C) {
-        float *dst = tile_stats + (size_t)blockIdx.y * 2 * C + c;
-        dst[0] = s;
-        dst[C] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+        const float m2t = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+        if (stats_acc > 0) {
+            float *dst = tile_stats + (size_t)(blockIdx.y % stats_acc) * 3 * C + c;
+            atomicAdd(dst, s);
+            atomicAdd(dst + C, m2t);
+            atomicAdd(dst + 2 * C, s * s / (float)nrows);
+        } else {
+            float *dst = tile_stats + (size_t)blockIdx.y * 2 * C + c;
+            dst[0] = s;
+            dst[C] = m2t;
+        }
     }
 }
 
@@ -766,6 +792,83 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T *__restrict__ x
         ss[c] = sc;
         ss[C + c] = beta[c] - save[c] * sc;
     }
+    __syncthreads();
+    if ((C & 3) == 0) {
+        const long long total4 = (long long)M * C / 4;
+        const int c4n = C / 4;
+        for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4;
+             i += (long long)gridDim.x * blockDim.x) {
+            const int c = (int)(i % c4n) * 4;
+            const float4 v = mpa_ld4<T>(x + 4 * i);
+            const float4 sc = *reinterpret_cast<const float4 *>(ss + c);
+            const float4 sh = *reinterpret_cast<const float4 *>(ss + C + c);
+            float4 o;
+            o.x = fmaf(v.x, sc.x, sh.x); o.y = fmaf(v.y, sc.y, sh.y);
+            o.z = fmaf(v.z, sc.z, sh.z); o.w = fmaf(v.w, sc.w, sh.w);
+            o.x = o.x > 0.f ? o.x : o.x * slope; o.y = o.y > 0.f ? o.y : o.y * slope;
+            o.z = o.z > 0.f ? o.z : o.z * slope; o.w = o.w > 0.f ? o.w : o.w * slope;
+            if (residual != nullptr) {
+                const float4 r = mpa_ld4<T>(residual + 4 * i);
+                o.x = r.x + o.x; o.y = r.y + o.y; o.z = r.z + o.z; o.w = r.w + o.w;
+            }
+            mpa_st4<T>(y + 4 * i, o);
+        }
+    } else {
+        const long long total = (long long)M * C;
+        for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+             i += (long long)gridDim.x * blockDim.x) {
+            const int c = (int)(i % C);
+            float t = fmaf(mpa_ld1<T>(x + i), ss[c], ss[C + c]);
+            t = t > 0.f ? t : t * slope;
+            mpa_st1<T>(y + i, residual != nullptr ? mpa_ld1<T>(residual + i) + t : t);
+        }
+    }
+}
+
+
+// y = residual + lrelu(bn(x)) with the BatchNorm statistics FINISHED IN THE PROLOGUE of every workgroup from the
+// sums the GEMM epilogues accumulated (stats [R][3][C]: sum, within-tile M2, sum^2/rows per 64-row tile):
+//   mean = S1/M,   M2 = S2 + (S3 - S1*mean)   (within tiles exactly, Chan's form; between tiles from the tile sums),
+// biased variance M2/M -- no separate finalize launch.  Workgroup 0 also stores (mean, invstd) for the backward
+// pass and updates the running statistics (momentum, unbiased variance) as nn.BatchNorm1d does.  Eval mode
+// (training == 0) normalises with the running statistics.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_stats_act_fwd_kernel(
+    const T *__restrict__ x, const float *__restrict__ stats, int R, int training, float *__restrict__ running_mean,
+    float *__restrict__ running_var, float momentum, float eps, long long *__restrict__ num_batches_tracked,
+    const float *__restrict__ gamma, const float *__restrict__ beta, const T *__restrict__ residual, float slope, int M,
+    int C, T *__restrict__ y, float *__restrict__ save)
+{
+    extern __shared__ float ss[];          // scale[C], shift[C]
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float mean, var;
+        if (training) {
+            float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            for (int r = 0; r < R; ++r) {
+                const float *p = stats + (size_t)r * 3 * C + c;
+                s1 += p[0]; s2 += p[C]; s3 += p[2 * C];
+            }
+            mean = s1 / (float)M;
+            var = fmaxf(0.f, (s2 + (s3 - s1 * mean)) / (float)M);
+        } else {
+            mean = running_mean[c];
+            var = running_var[c];
+        }
+        const float invstd = 1.0f / sqrtf(var + eps);
+        const float sc = gamma[c] * invstd;
+        ss[c] = sc;
+        ss[C + c] = beta[c] - mean * sc;
+        if (blockIdx.x == 0) {
+            save[c] = mean;
+            save[C + c] = invstd;
+            if (training && running_mean != nullptr) {
+                const float unb = M > 1 ? var * ((float)M / (float)(M - 1)) : var;
+                running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+                running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
+            }
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && training && num_batches_tracked != nullptr) *num_batches_tracked += 1;
     __syncthreads();
     if ((C & 3) == 0) {
         const long long total4 = (long long)M * C / 4;
@@ -1085,8 +1188,8 @@ static int launch_col_stats(const float *x, int M, int C, float *col_sum, float 
 
 extern "C" int mpa_gemm_f32(const float *A, int lda, int transA, const float *B, int ldb, int transB,
                             const float *bias, float *C, int ldc, int M, int N, int K, int accumulate,
-                            float *tile_stats, float *a_col_sum, float *workspace, size_t workspace_bytes,
-                            void *stream)
+                            float *tile_stats, int stats_replicas, float *a_col_sum, float *workspace,
+                            size_t workspace_bytes, void *stream)
 {
     MPA_CLEAR_ERROR();
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || lda <= 0 || ldb <= 0 || ldc < N) return MPA_EINVAL;
@@ -1102,17 +1205,17 @@ extern "C" int mpa_gemm_f32(const float *A, int lda, int transA, const float *B,
         if (K == KS) {
             if (transB)
                 hipLaunchKernelGGL((gemm_shortk_kernel<true, 1>), grid, dim3(NT), 32768, st, A, lda, B, ldb, bias, C, ldc,
-                                   M, N, tile_stats);
+                                   M, N, tile_stats, stats_replicas);
             else
                 hipLaunchKernelGGL((gemm_shortk_kernel<false, 1>), grid, dim3(NT), 32768, st, A, lda, B, ldb, bias, C, ldc,
-                                   M, N, tile_stats);
+                                   M, N, tile_stats, stats_replicas);
         } else {
             if (transB)
                 hipLaunchKernelGGL((gemm_shortk_kernel<true, 2>), grid, dim3(NT), 65536, st, A, lda, B, ldb, bias, C, ldc,
-                                   M, N, tile_stats);
+                                   M, N, tile_stats, stats_replicas);
             else
                 hipLaunchKernelGGL((gemm_shortk_kernel<false, 2>), grid, dim3(NT), 65536, st, A, lda, B, ldb, bias, C, ldc,
-                                   M, N, tile_stats);
+                                   M, N, tile_stats, stats_replicas);
         }
         MPA_LAUNCH_CHECK();
         return MPA_OK;
@@ -1158,16 +1261,16 @@ extern "C" int mpa_gemm_f32(const float *A, int lda, int transA, const float *B,
     int rc;
     if (transA && transB)
         rc = launch_gemm<true, true>(A, lda, B, ldb, bias, dst, ldc, M, N, K, splits, kchunk, out_mode, vecA, vecB,
-                                     stats, zero_c, a_col_sum, st);
+                                     stats, zero_c, a_col_sum, stats_replicas, st);
     else if (transA)
         rc = launch_gemm<true, false>(A, lda, B, ldb, bias, dst, ldc, M, N, K, splits, kchunk, out_mode, vecA, vecB,
-                                      stats, zero_c, a_col_sum, st);
+                                      stats, zero_c, a_col_sum, stats_replicas, st);
     else if (transB)
         rc = launch_gemm<false, true>(A, lda, B, ldb, bias, dst, ldc, M, N, K, splits, kchunk, out_mode, vecA, vecB,
-                                      stats, zero_c, a_col_sum, st);
+                                      stats, zero_c, a_col_sum, stats_replicas, st);
     else
         rc = launch_gemm<false, false>(A, lda, B, ldb, bias, dst, ldc, M, N, K, splits, kchunk, out_mode, vecA, vecB,
-                                       stats, zero_c, a_col_sum, st);
+                                       stats, zero_c, a_col_sum, stats_replicas, st);
     if (rc != MPA_OK) return rc;
     if (reduce_after) {
         const int gx = mpa_ceil_div((long long)mn, 256);
@@ -1179,7 +1282,7 @@ extern "C" int mpa_gemm_f32(const float *A, int lda, int transA, const float *B,
     if (stats_after) {
         if (accumulate) return MPA_EUNSUPPORTED;
         hipLaunchKernelGGL(tile_stats_kernel, dim3(mpa_ceil_div(N, 64), mpa_ceil_div(M, TS)), dim3(256), 0, st, C, M, N,
-                           tile_stats);
+                           tile_stats, stats_replicas);
     }
     MPA_LAUNCH_CHECK();
     return MPA_OK;
@@ -1277,7 +1380,7 @@ extern "C" int mpa_tile_stats_f32(const float *x, int M, int C, float *tile_stat
     MPA_CLEAR_ERROR();
     if (!x || !tile_stats || M <= 0 || C <= 0) return MPA_EINVAL;
     hipLaunchKernelGGL(tile_stats_kernel, dim3(mpa_ceil_div(C, 64), mpa_ceil_div(M, TS)), dim3(256), 0,
-                       (hipStream_t)stream, x, M, C, tile_stats);
+                       (hipStream_t)stream, x, M, C, tile_stats, 0);
     MPA_LAUNCH_CHECK();
     return MPA_OK;
 }
@@ -1446,4 +1549,48 @@ extern "C" int mpa_group_col_sum_f32(const float *x, int G, int R, int C, int ld
 extern "C" int mpa_group_col_sum_bf16(const mpa_bf16 *x, int G, int R, int C, int ld, float *out, void *stream)
 {
     return group_col_sum_any<bf16_t>(reinterpret_cast<const bf16_t *>(x), G, R, C, ld, out, stream);
+}
+
+template <typename T>
+static int bn_stats_act_fwd_any(const T *x, const float *stats, int replicas, int M, int C, float *running_mean,
+                                float *running_var, int training, float momentum, float eps,
+                                int64_t *num_batches_tracked, const float *gamma, const float *beta, const T *residual,
+                                float slope, T *y, float *save_mean_invstd, void *stream)
+{
+    MPA_CLEAR_ERROR();
+    if (!x || !gamma || !beta || !y || !save_mean_invstd || M <= 0 || C <= 0) return MPA_EINVAL;
+    if (training && (!stats || replicas <= 0)) return MPA_EINVAL;
+    if (!training && (!running_mean || !running_var)) return MPA_EINVAL;
+    if (C > 8192) return MPA_EUNSUPPORTED;
+    const bool al = (((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual) & mpa_vec4_align<T>::mask) == 0;
+    if ((C & 3) == 0 && !al) return MPA_EUNSUPPORTED;
+    long long total = (long long)M * C;
+    hipLaunchKernelGGL(bn_stats_act_fwd_kernel<T>, dim3(ew_grid(total / 4 + 1)), dim3(EW_TPB), 2 * C * sizeof(float),
+                       (hipStream_t)stream, x, stats, replicas, training, running_mean, running_var, momentum, eps,
+                       reinterpret_cast<long long *>(num_batches_tracked), gamma, beta, residual, slope, M, C, y,
+                       save_mean_invstd);
+    MPA_LAUNCH_CHECK();
+    return MPA_OK;
+}
+
+extern "C" int mpa_bn_stats_act_fwd_f32(const float *x, const float *stats, int replicas, int M, int C,
+                                        float *running_mean, float *running_var, int training, float momentum,
+                                        float eps, int64_t *num_batches_tracked, const float *gamma, const float *beta,
+                                        const float *residual, float slope, float *y, float *save_mean_invstd,
+                                        void *stream)
+{
+    return bn_stats_act_fwd_any<float>(x, stats, replicas, M, C, running_mean, running_var, training, momentum, eps,
+                                       num_batches_tracked, gamma, beta, residual, slope, y, save_mean_invstd, stream);
+}
+
+extern "C" int mpa_bn_stats_act_fwd_bf16(const mpa_bf16 *x, const float *stats, int replicas, int M, int C,
+                                         float *running_mean, float *running_var, int training, float momentum,
+                                         float eps, int64_t *num_batches_tracked, const float *gamma, const float *beta,
+                                         const mpa_bf16 *residual, float slope, mpa_bf16 *y, float *save_mean_invstd,
+                                         void *stream)
+{
+    return bn_stats_act_fwd_any<bf16_t>(reinterpret_cast<const bf16_t *>(x), stats, replicas, M, C, running_mean,
+                                        running_var, training, momentum, eps, num_batches_tracked, gamma, beta,
+                                        reinterpret_cast<const bf16_t *>(residual), slope, reinterpret_cast<bf16_t *>(y),
+                                        save_mean_invstd, stream);
 }

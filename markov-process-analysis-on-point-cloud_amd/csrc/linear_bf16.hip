@@ -212,7 +212,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const bf16_t *__restri
                                                           const TBm *__restrict__ Bm, int ldb,
                                                           const float *__restrict__ bias, void *__restrict__ Cv, int ldc,
                                                           int M, int N, int K, float *__restrict__ tile_stats,
-                                                          int vecA, int vecB, int vecC)
+                                                          int stats_acc, int vecA, int vecB, int vecC)
 {
     constexpr int NJ = GemmCfg<BN>::NJ;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -281,9 +281,16 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const bf16_t *__restri
             m2 += __shfl_xor(m2, 32, 64);
             const int col = n0 + wn * (BN / 2) + j * 32 + r31;
             if (half == 0 && col < N) {
-                float *dst = tile_stats + (size_t)(trow0 >> 6) * 2 * N + col;
-                dst[0] = s;
-                dst[N] = m2;
+                if (stats_acc > 0) {       // accumulate form [R][3][N] (see mpa_bn_stats_act_fwd)
+                    float *dst = tile_stats + (size_t)((trow0 >> 6) % stats_acc) * 3 * N + col;
+                    atomicAdd(dst, s);
+                    atomicAdd(dst + N, m2);
+                    atomicAdd(dst + 2 * N, s * s * inv);
+                } else {
+                    float *dst = tile_stats + (size_t)(trow0 >> 6) * 2 * N + col;
+                    dst[0] = s;
+                    dst[N] = m2;
+                }
             }
         }
     }
@@ -342,7 +349,7 @@ template <int BN> constexpr size_t gemm_bf16_lds()
 
 template <bool TB, int BN, typename TBm, bool OUT_F32>
 int launch_gemm_bf16(const bf16_t *A, int lda, const TBm *B, int ldb, const float *bias, void *C, int ldc, int M, int N,
-                     int K, float *stats, int vecA, int vecB, int vecC, hipStream_t st)
+                     int K, float *stats, int stats_acc, int vecA, int vecB, int vecC, hipStream_t st)
 {
     constexpr size_t lds = gemm_bf16_lds<BN>();
     auto kern = gemm_bf16_kernel<TB, BN, TBm, OUT_F32>;
@@ -356,20 +363,20 @@ int launch_gemm_bf16(const bf16_t *A, int lda, const TBm *B, int ldb, const floa
         }
     }
     const dim3 grid(mpa_ceil_div(M, BM) * mpa_ceil_div(N, BN));
-    hipLaunchKernelGGL(kern, grid, dim3(NT), lds, st, A, lda, B, ldb, bias, C, ldc, M, N, K, stats, vecA, vecB, vecC);
+    hipLaunchKernelGGL(kern, grid, dim3(NT), lds, st, A, lda, B, ldb, bias, C, ldc, M, N, K, stats, stats_acc, vecA, vecB, vecC);
     return MPA_OK;
 }
 
 template <bool TB, typename TBm, bool OUT_F32>
 int dispatch_bn(const bf16_t *A, int lda, const TBm *B, int ldb, const float *bias, void *C, int ldc, int M, int N, int K,
-                float *stats, int vecA, int vecB, int vecC, hipStream_t st)
+                float *stats, int stats_acc, int vecA, int vecB, int vecC, hipStream_t st)
 {
     // 128-column tiles halve the re-reads of A through L2; narrow outputs, small grids and widths that 128 does
     // not divide (a partial tile runs the element-wise edge loop) take 64
     const long long t128 = (long long)mpa_ceil_div(M, BM) * mpa_ceil_div(N, 128);
     if (N > 64 && t128 >= 192 && (N % 128 == 0 || N % 64 != 0))
-        return launch_gemm_bf16<TB, 128, TBm, OUT_F32>(A, lda, B, ldb, bias, C, ldc, M, N, K, stats, vecA, vecB, vecC, st);
-    return launch_gemm_bf16<TB, 64, TBm, OUT_F32>(A, lda, B, ldb, bias, C, ldc, M, N, K, stats, vecA, vecB, vecC, st);
+        return launch_gemm_bf16<TB, 128, TBm, OUT_F32>(A, lda, B, ldb, bias, C, ldc, M, N, K, stats, stats_acc, vecA, vecB, vecC, st);
+    return launch_gemm_bf16<TB, 64, TBm, OUT_F32>(A, lda, B, ldb, bias, C, ldc, M, N, K, stats, stats_acc, vecA, vecB, vecC, st);
 }
 
 // =============================================================================== weight gradients
@@ -504,7 +511,7 @@ __global__ __launch_bounds__(NT, 4) void gemm_bf16_tn_grouped_kernel(const TnArg
 
 extern "C" int mpa_gemm_bf16(const mpa_bf16 *A, int lda, const void *B, int ldb, int transB, int b_is_f32,
                              const float *bias, void *C, int ldc, int c_is_f32, int M, int N, int K,
-                             float *tile_stats, void *stream)
+                             float *tile_stats, int stats_replicas, void *stream)
 {
     MPA_CLEAR_ERROR();
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || lda < K || ldc < N || ldb < (transB ? K : N)) return MPA_EINVAL;
@@ -518,7 +525,7 @@ extern "C" int mpa_gemm_bf16(const mpa_bf16 *A, int lda, const void *B, int ldb,
     int rc;
 #define MPA_BF16_CASE(TB_, TBM_, OF32_)                                                                              \
     rc = dispatch_bn<TB_, TBM_, OF32_>(Ab, lda, reinterpret_cast<const TBM_ *>(B), ldb, bias, C, ldc, M, N, K,       \
-                                       tile_stats, vecA, vecB, vecC, st)
+                                       tile_stats, stats_replicas, vecA, vecB, vecC, st)
     if (transB) {
         if (b_is_f32) { if (c_is_f32) MPA_BF16_CASE(true, float, true); else MPA_BF16_CASE(true, float, false); }
         else { if (c_is_f32) MPA_BF16_CASE(true, bf16_t, true); else MPA_BF16_CASE(true, bf16_t, false); }

@@ -676,9 +676,10 @@ def _workspace(device, nbytes):
     return torch.empty(max((nbytes + 3) // 4, 4), dtype=torch.float32, device=device)
 
 
-def _gemm(A, lda, tA, Bm, ldb, tB, bias, C, ldc, M, N, K, accumulate=0, tile_stats=None, a_col_sum=None):
+def _gemm(A, lda, tA, Bm, ldb, tB, bias, C, ldc, M, N, K, accumulate=0, tile_stats=None, a_col_sum=None, stats_acc=0):
+    # stats_acc = R > 0: tile_stats is the pre-zeroed accumulate form [R][3][N] (see mpa_gemm_f32)
     if A.dtype == torch.bfloat16:
-        return _gemm_bf16(A, lda, tA, Bm, ldb, tB, bias, C, ldc, M, N, K, accumulate, tile_stats, a_col_sum)
+        return _gemm_bf16(A, lda, tA, Bm, ldb, tB, bias, C, ldc, M, N, K, accumulate, tile_stats, a_col_sum, stats_acc)
     ws, ws_bytes = None, 0
     ntiles = ((M + 63) // 64) * ((N + 63) // 64)
     if ntiles < 256 and K >= 512 and ldc == N:          # split-K partial tiles (see mpa_gemm_f32)
@@ -690,12 +691,12 @@ def _gemm(A, lda, tA, Bm, ldb, tB, bias, C, ldc, M, N, K, accumulate=0, tile_sta
     shortk = (not tA and not accumulate and a_col_sum is None and M % 64 == 0 and N % 64 == 0 and K in (64, 128)
               and lda % 4 == 0 and ldb % 4 == 0 and A.data_ptr() % 16 == 0 and Bm.data_ptr() % 16 == 0)
     _launch("mpa_gemm_f32", _p(A), lda, tA, _p(Bm), ldb, tB, _p(bias), _p(C), ldc, M, N, K, accumulate,
-            _p(tile_stats), _p(a_col_sum), _p(ws), ws_bytes, _stream(), algo_bytes=4 * (M * K + N * K + M * N),
+            _p(tile_stats), stats_acc, _p(a_col_sum), _p(ws), ws_bytes, _stream(), algo_bytes=4 * (M * K + N * K + M * N),
             algo_flops=2 * M * N * K, tag=(M, N, K, tA, tB, tile_stats is not None),
             variant="shortk" if shortk else "tiled")
 
 
-def _gemm_bf16(A, lda, tA, Bm, ldb, tB, bias, C, ldc, M, N, K, accumulate, tile_stats, a_col_sum):
+def _gemm_bf16(A, lda, tA, Bm, ldb, tB, bias, C, ldc, M, N, K, accumulate, tile_stats, a_col_sum, stats_acc=0):
     """The same products on bf16 features (mpa_gemm_bf16 / mpa_gemm_tn_grouped_bf16): A is a bf16 activation or
     gradient; B the fp32 master weight (forward, dX) or a bf16 activation (dW); C bf16, or fp32 for logits
     and weight gradients."""
@@ -711,7 +712,7 @@ def _gemm_bf16(A, lda, tA, Bm, ldb, tB, bias, C, ldc, M, N, K, accumulate, tile_
     b32 = Bm.dtype == torch.float32
     c32 = C.dtype == torch.float32
     _launch("mpa_gemm_bf16", _p(A), lda, _p(Bm), ldb, 1 if tB else 0, int(b32), _p(bias), _p(C), ldc, int(c32), M, N, K,
-            _p(tile_stats), _stream(), algo_bytes=2 * M * K + (4 if b32 else 2) * N * K + (4 if c32 else 2) * M * N,
+            _p(tile_stats), stats_acc, _stream(), algo_bytes=2 * M * K + (4 if b32 else 2) * N * K + (4 if c32 else 2) * M * N,
             algo_flops=2 * M * N * K, tag=(M, N, K, tA, tB, tile_stats is not None))
 
 
@@ -1031,6 +1032,68 @@ def linear_stack(x, layers, zero_bias):
 _BN_REPLICAS = 8
 
 
+class ZeroArena:
+    """Pre-zeroed fp32 scratch for the accumulators of one training pass (BatchNorm statistics that GEMM epilogues
+    add into, the channel sums of the BatchNorm backward): take(n) hands out the next n floats, begin() clears
+    what the previous pass used with ONE fill and rewinds.  Inside a captured HIP graph the buffer is persistent
+    (allocated before the capture, kept alive by the arena) and the fill is the graph's first node, so every
+    replay starts from zeros.  Outside a managed pass -- plain eager use of the ops -- take() falls back to
+    torch.zeros (one fill per request)."""
+
+    def __init__(self, device, nfloats=1 << 22):
+        self.buf = torch.zeros(nfloats, dtype=torch.float32, device=device)
+        self.cursor = 0
+        self.high = 0
+        self.active = False
+
+    def begin(self):
+        if self.high:
+            self.buf[:self.high].zero_()
+        self.cursor = 0
+        self.active = True
+
+    def end(self):
+        self.high = max(self.high, self.cursor)
+        self.active = False
+
+    def take(self, n, device):
+        n64 = (n + 63) // 64 * 64                    # slices start on 256-byte boundaries
+        if not self.active or self.buf.device != device or self.cursor + n64 > self.buf.numel():
+            return torch.zeros(n, dtype=torch.float32, device=device)
+        s = self.buf[self.cursor:self.cursor + n]
+        self.cursor += n64
+        self.high = max(self.high, self.cursor)
+        return s
+
+
+_ARENA = None
+# BatchNorm statistics: the default path accumulates the tiles' sums with float atomics (no finalize launch); the
+# order of the adds varies from run to run, so two runs of the same step agree to fp32 rounding, not bit for
+# bit (and the nets amplify that: max / LeakyReLU selections flip).  DETERMINISTIC_BN = True selects the
+# per-tile statistics + mpa_bn_finalize_f32 path instead (fixed merge order, one more launch per Linear unit).
+DETERMINISTIC_BN = False
+
+
+def set_deterministic(on=True):
+    """Bit-reproducible BatchNorm statistics (per-tile pairs merged in a fixed order by mpa_bn_finalize_f32)
+    instead of the default atomically accumulated sums.  Returns the previous setting."""
+    global DETERMINISTIC_BN
+    old, DETERMINISTIC_BN = DETERMINISTIC_BN, bool(on)
+    return old
+
+
+def set_arena(arena):
+    """Install (or remove, None) the ZeroArena the Linear units draw their accumulators from."""
+    global _ARENA
+    _ARENA = arena
+
+
+def _zeros_acc(n, device):
+    if _ARENA is not None:
+        return _ARENA.take(n, device)
+    return torch.zeros(n, dtype=torch.float32, device=device)
+
+
 class _LinearBNAct(torch.autograd.Function):
     """Linear -> BatchNorm1d over the rows -> LeakyReLU (+ residual), as one unit: the GEMM epilogue
     yields the batch statistics, one elementwise kernel normalises + activates (+ adds the
@@ -1042,19 +1105,31 @@ class _LinearBNAct(torch.autograd.Function):
         N = W.shape[0]
         dev = x.device
         y = torch.empty(M, N, dtype=x.dtype, device=dev)
-        stats = torch.empty((M + 63) // 64, 2, N, dtype=torch.float32, device=dev) if training else None
-        _gemm(x, K, 0, W, K, 1, b, y, N, M, N, K, 0, stats)
+        # batch statistics: every 64-row tile of the GEMM adds its (sum, within-tile M2, sum^2/rows) per column into
+        # a pre-zeroed [R][3][N] accumulator (R replicas spread the float atomics of the many-tile layers); the
+        # normalise kernel finishes mean / variance in its prologue -- no separate finalize launch
         out = torch.empty(M, N, dtype=x.dtype, device=dev)
         saved = torch.empty(2, N, dtype=torch.float32, device=dev)
         direct = (_direct(W), _direct(b), _direct(gamma), _direct(beta))
         need = any(ctx.needs_input_grad)
-        # sums: [_BN_REPLICAS][2][N] accumulator of backward's channel reductions (float atomics spread
-        # over replicas), cleared here for free
-        sums = torch.empty(_BN_REPLICAS, 2, N, dtype=torch.float32, device=dev) if need else None
-        _launch("mpa_bn_finalize_f32", _p(stats), M, N, _p(running_mean), _p(running_var), int(training),
-                float(momentum), float(eps), _p(saved), _p(sums), _BN_REPLICAS * 2 * N, _p(nbt), _stream())
-        _launch("mpa_bn_act_fwd_" + _sfx(y), _p(y), _p(saved), _p(gamma), _p(beta), _p(residual), float(slope), M, N,
-                _p(out), _stream())
+        if DETERMINISTIC_BN:
+            # per-tile (sum, M2) pairs, merged in a fixed order by a finalize launch (which also clears `sums`)
+            stats = torch.empty((M + 63) // 64, 2, N, dtype=torch.float32, device=dev) if training else None
+            _gemm(x, K, 0, W, K, 1, b, y, N, M, N, K, 0, stats)
+            sums = torch.empty(_BN_REPLICAS, 2, N, dtype=torch.float32, device=dev) if need else None
+            _launch("mpa_bn_finalize_f32", _p(stats), M, N, _p(running_mean), _p(running_var), int(training),
+                    float(momentum), float(eps), _p(saved), _p(sums), _BN_REPLICAS * 2 * N, _p(nbt), _stream())
+            _launch("mpa_bn_act_fwd_" + _sfx(y), _p(y), _p(saved), _p(gamma), _p(beta), _p(residual), float(slope), M, N,
+                    _p(out), _stream())
+        else:
+            R = 8 if (M + 63) // 64 >= 256 else 1
+            stats = _zeros_acc(R * 3 * N, dev) if training else None
+            _gemm(x, K, 0, W, K, 1, b, y, N, M, N, K, 0, stats, stats_acc=R)
+            # sums: [_BN_REPLICAS][2][N] accumulator of backward's channel reductions (atomics spread over replicas)
+            sums = _zeros_acc(_BN_REPLICAS * 2 * N, dev).view(_BN_REPLICAS, 2, N) if need else None
+            _launch("mpa_bn_stats_act_fwd_" + _sfx(y), _p(y), _p(stats), R, M, N, _p(running_mean), _p(running_var),
+                    int(training), float(momentum), float(eps), _p(nbt), _p(gamma), _p(beta), _p(residual), float(slope),
+                    _p(out), _p(saved), _stream())
         ctx.save_for_backward(x, W, y, gamma, beta, saved, sums)
         ctx.cfg = (bool(training), float(slope), b is not None, residual is not None)
         ctx.direct = direct

@@ -115,6 +115,7 @@ class GraphedTrainStep:
         self.compute_loss = compute_loss
         self.static = [t.clone() for t in example_batch]
         self.feeder = FpsStartFeeder()
+        self.arena = ops.ZeroArena(self.static[0].device)       # the pass's pre-zeroed accumulators (one fill per step)
         self.reducer = GradReducer(model, bucket_bytes=bucket_bytes, direct=True)
         self.reducer.overlap = False
         ops.set_fps_start_hook(self.feeder)
@@ -145,6 +146,8 @@ class GraphedTrainStep:
     def _fwd_bwd(self):
         self.feeder.begin_pass()
         self.reducer.zero_grad()
+        self.arena.begin()
+        ops.set_arena(self.arena)
         try:
             if self.compute_loss is not None:
                 loss = self.compute_loss(self.model, self.loss_fn, *self.static)
@@ -152,6 +155,8 @@ class GraphedTrainStep:
                 loss = self.loss_fn(self.model(self.static[0]), *self.static[1:])
         finally:
             self.feeder.end_pass()
+            ops.set_arena(None)
+            self.arena.end()
         ops.defer_weight_grads(True)          # dW products are queued during backward ...
         try:
             loss.backward()

@@ -74,12 +74,12 @@ def test_gemm_bf16_forward_and_dx(lib, M, N, K, b_f32):
     scale = float(ref.abs().max())
     C32 = torch.full((M, N), float("nan"), device="cuda")
     stats = torch.full(((M + 63) // 64, 2, N), float("nan"), device="cuda")
-    rc = lib.mpa_gemm_bf16(p(A), K, p(Wd), K, 1, int(b_f32), p(bias), p(C32), N, 1, M, N, K, p(stats), None)
+    rc = lib.mpa_gemm_bf16(p(A), K, p(Wd), K, 1, int(b_f32), p(bias), p(C32), N, 1, M, N, K, p(stats), 0, None)
     assert rc == 0
     torch.cuda.synchronize()
     assert float((C32.double() - ref).abs().max()) <= 2e-6 * scale * max(1.0, K ** 0.5 / 8), "fp32 output"
     C16 = torch.zeros(M, N, dtype=BF, device="cuda")
-    assert lib.mpa_gemm_bf16(p(A), K, p(Wd), K, 1, int(b_f32), p(bias), p(C16), N, 0, M, N, K, None, None) == 0
+    assert lib.mpa_gemm_bf16(p(A), K, p(Wd), K, 1, int(b_f32), p(bias), p(C16), N, 0, M, N, K, None, 0, None) == 0
     torch.cuda.synchronize()
     assert torch.equal(C16, C32.to(BF)), "bf16 output is the fp32 result rounded once"
     # tile statistics: per 64-row tile the sum and the sum of squared deviations from the tile mean
@@ -92,12 +92,12 @@ def test_gemm_bf16_forward_and_dx(lib, M, N, K, b_f32):
     Gy = torch.randn(M, N, generator=g).to(BF).cuda()
     refx = Gy.double() @ Wr
     X32 = torch.full((M, K), float("nan"), device="cuda")
-    assert lib.mpa_gemm_bf16(p(Gy), N, p(Wd), K, 0, int(b_f32), None, p(X32), K, 1, M, K, N, None, None) == 0
+    assert lib.mpa_gemm_bf16(p(Gy), N, p(Wd), K, 0, int(b_f32), None, p(X32), K, 1, M, K, N, None, 0, None) == 0
     torch.cuda.synchronize()
     assert float((X32.double() - refx).abs().max()) <= 2e-6 * float(refx.abs().max()) * max(1.0, N ** 0.5 / 8), "dX"
     if K % 2 == 0:
         X16 = torch.zeros(M, K, dtype=BF, device="cuda")
-        assert lib.mpa_gemm_bf16(p(Gy), N, p(Wd), K, 0, int(b_f32), None, p(X16), K, 0, M, K, N, None, None) == 0
+        assert lib.mpa_gemm_bf16(p(Gy), N, p(Wd), K, 0, int(b_f32), None, p(X16), K, 0, M, K, N, None, 0, None) == 0
         torch.cuda.synchronize()
         assert torch.equal(X16, X32.to(BF))
 
@@ -111,7 +111,7 @@ def test_gemm_bf16_strided_rows(lib):
     Cwide = torch.zeros(M, 2 * N, dtype=BF, device="cuda")
     A = Awide[:, K:2 * K]
     rc = lib.mpa_gemm_bf16(ctypes.c_void_p(A.data_ptr()), 3 * K, p(W), K, 1, 1, None,
-                           ctypes.c_void_p(Cwide.data_ptr() + 2 * N), 2 * N, 0, M, N, K, None, None)
+                           ctypes.c_void_p(Cwide.data_ptr() + 2 * N), 2 * N, 0, M, N, K, None, 0, None)
     assert rc == 0
     torch.cuda.synchronize()
     ref = (A.double() @ W.to(BF).double().t())

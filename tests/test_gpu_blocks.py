@@ -378,7 +378,17 @@ def test_seg_model(P, golden_seg):
     _check_grads(g, model)
 
 
-def test_direct_grad_mode_matches_autograd(P, RS, golden_cls):
+@pytest.fixture
+def deterministic_bn():
+    """Two RUNS of one step are compared: with the default (atomically accumulated) BatchNorm sums they agree to
+    rounding only, and the net amplifies rounding through its max selections -- pin the merge order."""
+    import mpa_amd.ops as _ops
+    was = _ops.set_deterministic(True)
+    yield
+    _ops.set_deterministic(was)
+
+
+def test_direct_grad_mode_matches_autograd(P, RS, golden_cls, deterministic_bn):
     """GradReducer(direct=True): backward kernels write parameter gradients straight into the flat
     buckets.  Same numbers as handing them to autograd, and the same set of parameters."""
     from mpa_amd.models.repsurf.repsurf_ssg_umb import Model
@@ -504,7 +514,7 @@ def _small_cls_step(lr=1e-3, B=4):
     return model, GraphedTrainStep(model, SmoothClsLoss(), (x, y), lr=lr), x, y
 
 
-def test_graphed_step_follows_the_learning_rate_schedule():
+def test_graphed_step_follows_the_learning_rate_schedule(deterministic_bn):
     """The learning rate is a device scalar of the captured optimizer graph: a torch scheduler attached to
     FlatAdam changes the step size of later replays (the reference steps StepLR / CosineAnnealingLR every
     epoch, tool/train_cls_scanobjectnn.py:219-238).  Adam's update is lr * m_hat / (sqrt(v_hat) + eps), so

@@ -126,3 +126,79 @@ def test_partseg_wiring_at_4096_points(ops, monkeypatch):
         full, _ = model(x, label)
         one, _ = model(x[1:2].contiguous(), label[1:2].contiguous())
     assert torch.allclose(full[1:2], one, rtol=1e-4, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------- bf16 feature path at full size
+def test_partseg_bf16_full_batch_step():
+    """BASELINE configs[2] at its full size -- part segmentation, 2048 points, batch 32, bf16 features -- through
+    the captured training step: finite and falling loss, every live parameter receives a finite fp32 gradient,
+    logits fp32.  (Numerics against the fp32 fixtures: tests/test_gpu_bf16.py; parity unpinned for bf16.)"""
+    import mpa_amd  # noqa: F401
+    from mpa_amd import ops
+    from mpa_amd.models.repsurf.pointnet2_part_seg_msg import get_model, get_loss
+    from mpa_amd.runtime import GraphedTrainStep
+    B, N = 32, 2048
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(11)
+    x = unit_cloud(B, N, seed=11).transpose(1, 2).contiguous().to(dev)
+    label = torch.zeros(B, 1, 16)
+    label[torch.arange(B), 0, torch.randint(0, 16, (B,), generator=g)] = 1
+    label = label.to(dev)
+    target = torch.randint(0, 50, (B, N), generator=g).to(dev)
+    torch.manual_seed(0)
+    model = get_model(50).to(dev).train()
+
+    def compute_loss(model, crit, x, label, target):
+        pred, _ = model(x, label)
+        assert pred.dtype == torch.float32 and pred.shape == (B, N, 50)
+        return crit(pred.reshape(-1, 50), target.reshape(-1))
+
+    with ops.feature_dtype(torch.bfloat16):
+        step = GraphedTrainStep(model, get_loss(), (x, label, target), lr=1e-3, compute_loss=compute_loss)
+        try:
+            losses = [float(step(x, label, target).detach()) for _ in range(10)]
+            torch.cuda.synchronize()
+            live = [p for p in model.parameters() if p.grad is not None]
+            assert len(live) > 400 and all(p.grad.dtype == torch.float32 and torch.isfinite(p.grad).all() for p in live)
+            assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+        finally:
+            step.close()
+
+
+def test_completion_chain_16384_bf16(ops):
+    """BASELINE configs[4]'s op chain 1024 -> 2048 -> 4096 -> 8192 -> 16384 points (B = 8, C = 64) on bf16 features:
+    kNN on the rounded features' exact values, `upsample` forward / backward and the difference attention on a
+    16,384-point state -- each equal to the fp32 op on the same rounded inputs, rounded once (the reference has
+    no model for this configuration and no bf16 numerics: op-level, parity unpinned)."""
+    B, C, K = 8, 64, 8
+    g = torch.Generator().manual_seed(3)
+    xyz = unit_cloud(B, 16384, seed=5).cuda()
+    feats = torch.randn(B, 1024, C, generator=g).to(torch.bfloat16).cuda()
+    lvl = [16384 >> s for s in (4, 3, 2, 1, 0)]           # 1024 ... 16384
+    cur16, cur32 = feats.clone().requires_grad_(True), feats.float().requires_grad_(True)
+    f16, f32 = cur16, cur32
+    for i in range(4):
+        coarse, fine = xyz[:, :lvl[i]].contiguous(), xyz[:, :lvl[i + 1]].contiguous()
+        idx = ops.knn_point(K, fine, coarse)[1]            # coarse rows list their K nearest fine points
+        f16, f32 = ops.upsample(f16, idx), ops.upsample(f32, idx)
+        assert f16.dtype == torch.bfloat16 and f16.shape == (B, lvl[i + 1], C)
+        assert torch.equal(f16, f32.to(torch.bfloat16)), i
+        f32 = f16.float()                                  # (keep the two chains on identical inputs)
+    q = torch.randn(B, 16384, C, generator=g).to(torch.bfloat16).cuda()
+    kv = torch.cat((f16, f16 * 0.5), 2).contiguous()
+    nidx = ops.knn_point(K, xyz, xyz)[1]
+    o16 = ops.diffattn(q, kv, nidx)
+    o32 = ops.diffattn(q.float(), kv.float(), nidx)
+    assert torch.equal(o16, o32.to(torch.bfloat16))
+    # feature-space search on bf16 features = the fp32 search on their exact values (bit-exact indices)
+    d16, i16 = ops.knn_point(K, f16[:, :4096].contiguous(), f16[:, :2048].contiguous())
+    d32, i32 = ops.knn_point(K, f16[:, :4096].float().contiguous(), f16[:, :2048].float().contiguous())
+    assert torch.equal(i16, i32) and torch.equal(d16, d32)
+    # backward through one upsample at the largest state
+    w = torch.randn(B, 16384, C, generator=g).to(torch.bfloat16).cuda()
+    p16 = feats.new_zeros(B, 8192, C).copy_(torch.randn(B, 8192, C, generator=g)).requires_grad_(True)
+    p32 = p16.detach().float().requires_grad_(True)
+    idx = ops.knn_point(K, xyz, xyz[:, :8192].contiguous())[1]
+    ops.upsample(p16, idx).backward(w)
+    ops.upsample(p32, idx).backward(w.float())
+    assert torch.equal(p16.grad, p32.grad.to(torch.bfloat16))

@@ -46,7 +46,7 @@ int main()
         int lda = s.tA ? s.M : s.K, ldb = s.tB ? s.K : s.N;
         auto run = [&]() {
             return mpa_gemm_f32(A, lda, s.tA, B, ldb, s.tB, s.tA ? nullptr : bias, C, s.N, s.M, s.N, s.K, 0,
-                                (s.stats && !getenv("NOSTATS")) ? st : nullptr, nullptr, getenv("NOWS") ? nullptr : ws,
+                                (s.stats && !getenv("NOSTATS")) ? st : nullptr, 0, nullptr, getenv("NOWS") ? nullptr : ws,
                                 (size_t)64 << 20, nullptr);
         };
         for (int i = 0; i < 3; ++i) if (run() != 0) { printf("launch failed\n"); return 1; }

@@ -4,8 +4,22 @@ HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB -> bytes (the x2 on FETCH
 correction of MI355X_MICROARCH.md for 16-B-per-lane streams)."""
 import collections
 import csv
+import glob
+import hashlib
 import json
+import os
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def kernel_sources_sha():          # same definition as bench.py's
+    h = hashlib.sha256()
+    for path in sorted(glob.glob(os.path.join(ROOT, "markov-process-analysis-on-point-cloud_amd", "csrc", "*.h*"))):
+        h.update(os.path.basename(path).encode())
+        h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
+
 
 ENTRY = {          # C-ABI entry point -> (main kernel prefix, helper kernel prefixes)
     "mpa_gemm_f32/tiled": ("gemm_kernel<", ["splitk_reduce_kernel"]),
@@ -14,6 +28,10 @@ ENTRY = {          # C-ABI entry point -> (main kernel prefix, helper kernel pre
     "mpa_knn_f32": ("knn_mfma_kernel<", []),
     "mpa_diffattn_fwd_f32": ("diffattn_fwd", []),
     "mpa_diffattn_bwd_f32": ("diffattn_bwd_p1", ["diffattn_bwd_p2", "csr_build_kernel"]),
+    "mpa_gemm_bf16": ("gemm_bf16_kernel<", []),
+    "mpa_gemm_tn_grouped_bf16": ("gemm_bf16_tn_grouped_kernel", ["splitk_reduce_grouped_kernel"]),
+    "mpa_diffattn_fwd_bf16": ("diffattn_fwd", []),
+    "mpa_diffattn_bwd_bf16": ("diffattn_bwd_p1", ["diffattn_bwd_p2", "csr_build_kernel"]),
     "mpa_fps_f32": ("fps_kernel<", []),
     "mpa_bn_act_fwd_f32": ("bn_act_fwd_kernel", []),
 }
@@ -24,6 +42,10 @@ def load(path):
     seen = set()
     for r in csv.DictReader(open(path)):
         k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+        if k.startswith("_ZN12_GLOBAL__N_1"):          # a mangled name rocprofv3 left as is: <len><name>...
+            rest = k[len("_ZN12_GLOBAL__N_1"):]
+            n = int("".join(c for c in rest[:3] if c.isdigit()))
+            k = rest[len(str(n)):len(str(n)) + n] + "<"
         tot[k] += float(r["Counter_Value"])
         key = (k, r.get("Dispatch_Id"))
         if key not in seen:
@@ -38,7 +60,7 @@ out = {"how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passe
               "KiB; per-launch averages over every dispatch of the run; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 "
               "-- the x2 on FETCH_SIZE is the gfx950 correction of MI355X_MICROARCH.md (calibrated for 16-B-per-lane "
               "streams; uncalibrated for narrower loads)." % sys.argv[4],
-       "kernels": {}, "by_device_kernel": {}}
+       "kernel_sources_sha": kernel_sources_sha(), "kernels": {}, "by_device_kernel": {}}
 for k in sorted(fetch, key=lambda k: -(2 * fetch[k] + write.get(k, 0))):
     n = max(fcnt[k], 1)
     out["by_device_kernel"][k] = {"launches": fcnt[k], "fetch_kib_per_launch": fetch[k] / n,
