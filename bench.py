@@ -271,7 +271,13 @@ def main():
     else:
         # the whole forward+backward is one HIP graph; all-reduce + (graphed) Adam follow it
         from mpa_amd.runtime import GraphedTrainStep
-        graphed = GraphedTrainStep(model, crit, data, lr=1e-3, compute_loss=compute_loss)   # optim.FlatAdam on flat buckets
+        # MPA_CAPTURE_REDUCE=1 (N > 1): flush the weight gradients of head / la5 / la4 (96 % of the bytes) early and
+        # all-reduce them INSIDE the captured graph, overlapped with the rest of backward.  Off by default: RCCL under
+        # graph capture could not be exercised on the one-GPU boxes this was developed on.
+        cap = world > 1 and os.environ.get("MPA_CAPTURE_REDUCE") == "1"
+        split = (model.keepHigh.la4 if cap else None)
+        graphed = GraphedTrainStep(model, crit, data, lr=1e-3, compute_loss=compute_loss, split_after=split,
+                                   capture_reduce=cap)                # optim.FlatAdam on the flat buckets
 
         def step():
             return graphed(*data)

@@ -38,8 +38,14 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int *wave_tot, int &t
     return base + x - v;
 }
 
+// Per-cloud queue of "hub" rows (rows listed by very many entries): [B][CSR_QUEUE_INTS] ints = reserved count,
+// head, CSR_QUEUE_MAX row slots.  Cleared here (optional), filled and drained by the consumer kernel.
+constexpr int CSR_QUEUE_MAX = 254;
+constexpr int CSR_QUEUE_INTS = CSR_QUEUE_MAX + 2;
+
 __global__ __launch_bounds__(CSR_TPB) void csr_build_kernel(const int64_t *__restrict__ idx, int N, int SK, int range,
-                                                             int *__restrict__ rowptr, int *__restrict__ entries)
+                                                             int *__restrict__ rowptr, int *__restrict__ entries,
+                                                             int *__restrict__ queue)
 {
     extern __shared__ int csr_lds[];       // cnt[range] | pos[range]
     __shared__ int wave_tot[CSR_TPB / 64];
@@ -51,6 +57,8 @@ __global__ __launch_bounds__(CSR_TPB) void csr_build_kernel(const int64_t *__res
     int *rp = rowptr + (size_t)b * (N + 1);
     int *en = entries + (size_t)b * SK;
     for (int r = tid; r < range; r += CSR_TPB) cnt[r] = 0;
+    if (queue != nullptr && blockIdx.x == 0)
+        for (int i = tid; i < CSR_QUEUE_INTS; i += CSR_TPB) queue[(size_t)b * CSR_QUEUE_INTS + i] = i < 2 ? 0 : -1;
     __syncthreads();
     int rr[EPT];
     const bool one_chunk = SK <= EPT * CSR_TPB;
@@ -97,13 +105,14 @@ __global__ __launch_bounds__(CSR_TPB) void csr_build_kernel(const int64_t *__res
     }
 }
 
-inline void launch_csr_build(const int64_t *idx, int B, int N, int SK, int *rowptr, int *entries, hipStream_t st)
+inline void launch_csr_build(const int64_t *idx, int B, int N, int SK, int *rowptr, int *entries, hipStream_t st,
+                             int *queue = nullptr)
 {
     int ranges = 1;                                       // workgroups per cloud: ~256 rows each, >= 256 in all
     while (ranges < 64 && (N / ranges > 256 || B * ranges < 256) && N / (2 * ranges) >= 32) ranges <<= 1;
     const int range = (N + ranges - 1) / ranges;
     hipLaunchKernelGGL(csr_build_kernel, dim3(mpa_ceil_div(N, range), B), dim3(CSR_TPB),
-                       (size_t)2 * range * sizeof(int), st, idx, N, SK, range, rowptr, entries);
+                       (size_t)2 * range * sizeof(int), st, idx, N, SK, range, rowptr, entries, queue);
 }
 
 }  // namespace

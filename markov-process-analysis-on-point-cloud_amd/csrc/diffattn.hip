@@ -336,10 +336,11 @@ template <int V, typename TF>
 __global__ __launch_bounds__(TPB) void diffattn_bwd_p2_kernel(
     const TF *__restrict__ T, const TF *__restrict__ Tv, const uint8_t *__restrict__ argk,
     const int *__restrict__ rowptr, const int *__restrict__ entries, int N, int S, int K, int C, int lanes_per_row,
-    TF *__restrict__ gk, TF *__restrict__ gv, int ldg)
+    TF *__restrict__ gk, TF *__restrict__ gv, int ldg, int *__restrict__ queue)
 {
     __shared__ int long_rows[TPB];
     __shared__ int n_long;
+    __shared__ int job;
     __shared__ float red[2 * V * TPB];
     const int rl = threadIdx.x / lanes_per_row, cl = threadIdx.x % lanes_per_row;
     const int rpb = TPB / lanes_per_row;
@@ -430,17 +431,70 @@ __global__ __launch_bounds__(TPB) void diffattn_bwd_p2_kernel(
         }
     }
     __syncthreads();
-    const int nl = n_long;
-    for (int li = 0; li < nl; ++li) {
-        const int row = long_rows[li];
+    // ---- hub rows.  They tend to sit next to each other (ties resolve to the lowest indices), i.e. in ONE
+    // workgroup's row range: processed there one after the other they cost hundreds of microseconds while the rest
+    // of the chip idles.  So every workgroup posts its hub rows to the cloud's queue and then drains the queue
+    // together with the cloud's other workgroups (each job = one row, summed by a whole workgroup).  A job is
+    // never lost: whoever posts drains afterwards until the queue is empty.
+    int *qb = queue + (size_t)b * CSR_QUEUE_INTS;        // [0] posted, [1] taken, [2..] rows (-1 = not yet written)
+    int nl = n_long;
+    if (threadIdx.x == 0) {
+        int kept = 0;
+        for (int li = 0; li < nl; ++li) {
+            const int slot = __hip_atomic_fetch_add(qb, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (slot < CSR_QUEUE_MAX)
+                __hip_atomic_store(qb + 2 + slot, long_rows[li], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else
+                long_rows[kept++] = long_rows[li];           // queue full: stays with this workgroup
+        }
+        n_long = kept;
+    }
+    __syncthreads();
+    nl = n_long;
+    for (int li = 0;; ++li) {
+        if (threadIdx.x == 0) {
+            int row = -1;
+            if (li < nl) {
+                row = long_rows[li];
+            } else {
+                for (;;) {
+                    const int posted = min(__hip_atomic_load(qb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), CSR_QUEUE_MAX);
+                    int taken = __hip_atomic_load(qb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (taken >= posted) break;
+                    if (__hip_atomic_compare_exchange_strong(qb + 1, &taken, taken + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_AGENT)) {
+                        // the slot was reserved before `posted` was read; its row is written right after the
+                        // reservation: wait for it (bounded)
+                        for (int spin = 0; spin < (1 << 20); ++spin) {
+                            row = __hip_atomic_load(qb + 2 + taken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (row >= 0) break;
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                        break;
+                    }
+                }
+            }
+            job = row;
+        }
+        __syncthreads();
+        const int row = job;
+        if (row < 0) break;
         const int beg = rp[row], end = rp[row + 1];
         for (int c0 = 0; c0 < C; c0 += lanes_per_row * V) {
             const int c = c0 + cl * V;
             float ak[V], av[V];
 #pragma unroll
             for (int u = 0; u < V; ++u) ak[u] = av[u] = 0.f;
-            if (c < C)
-                for (int e = beg + rl; e < end; e += rpb) add_entry((unsigned)en[e], c, ak, av);
+            if (c < C) {
+                for (int e0 = beg + rl; e0 < end; e0 += 4 * rpb) {         // four entries in flight per lane
+                    unsigned ent[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) ent[u] = (unsigned)en[min(e0 + u * rpb, end - 1)];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (e0 + u * rpb < end) add_entry(ent[u], c, ak, av);
+                }
+            }
 #pragma unroll
             for (int u = 0; u < V; ++u) {
                 red[(u * 2) * TPB + threadIdx.x] = ak[u];
@@ -682,7 +736,7 @@ extern "C" int mpa_diffattn_fwd_bf16(const mpa_bf16 *q, int ldq, const mpa_bf16 
 
 namespace {
 struct BwdWorkspace {
-    size_t t_off, tv_off, rowptr_off, entries_off, total;
+    size_t t_off, tv_off, rowptr_off, entries_off, queue_off, total;
 };
 inline BwdWorkspace bwd_workspace(int B, int N, int S, int K, int C, size_t esz)
 {
@@ -692,7 +746,8 @@ inline BwdWorkspace bwd_workspace(int B, int N, int S, int K, int C, size_t esz)
     w.tv_off = up((size_t)B * S * K * C * esz);
     w.rowptr_off = w.tv_off + up((size_t)B * S * C * esz);
     w.entries_off = w.rowptr_off + up((size_t)B * (N + 1) * 4);
-    w.total = w.entries_off + up((size_t)B * S * K * 4);
+    w.queue_off = w.entries_off + up((size_t)B * S * K * 4);
+    w.total = w.queue_off + up((size_t)B * CSR_QUEUE_INTS * 4);
     return w;
 }
 inline bool bwd_workspace_ok(int B, int N, int S, int K, int C)
@@ -734,7 +789,8 @@ static int diffattn_bwd_any(const TF *q, int ldq, const TF *k, const TF *v, int 
         TF *Tv = reinterpret_cast<TF *>((char *)workspace + w.tv_off);
         int *rowptr = reinterpret_cast<int *>((char *)workspace + w.rowptr_off);
         int *entries = reinterpret_cast<int *>((char *)workspace + w.entries_off);
-        launch_csr_build(idx, B, N, S * K, rowptr, entries, st);
+        int *queue = reinterpret_cast<int *>((char *)workspace + w.queue_off);
+        launch_csr_build(idx, B, N, S * K, rowptr, entries, st, queue);
         static const bool scalar_only = getenv("MPA_DIFFATTN_SCALAR") != nullptr;
         const bool p1v4 = (!scalar_only || !F32) && (C & 3) == 0 && (ldkv & 3) == 0 && (ldq & 3) == 0 &&
                           ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)grad_ctx | (uintptr_t)grad_q) &
@@ -763,10 +819,10 @@ static int diffattn_bwd_any(const TF *q, int ldq, const TF *k, const TF *v, int 
         const dim3 grid2(mpa_ceil_div(N, TPB / lanes), B);
         if (v4)
             hipLaunchKernelGGL((diffattn_bwd_p2_kernel<4, TF>), grid2, dim3(TPB), 0, st, T, Tv, argk, rowptr, entries, N, S,
-                               K, C, lanes, grad_k, grad_v, ldg);
+                               K, C, lanes, grad_k, grad_v, ldg, queue);
         else
             hipLaunchKernelGGL((diffattn_bwd_p2_kernel<1, TF>), grid2, dim3(TPB), 0, st, T, Tv, argk, rowptr, entries, N, S,
-                               K, C, lanes, grad_k, grad_v, ldg);
+                               K, C, lanes, grad_k, grad_v, ldg, queue);
         MPA_LAUNCH_CHECK();
         return MPA_OK;
     }

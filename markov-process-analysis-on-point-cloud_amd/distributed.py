@@ -82,7 +82,7 @@ class GradReducer:
     The first backward discovers which parameters receive gradients; from then on their .grad
     tensors are views into flat buckets and reductions start from autograd hooks."""
 
-    def __init__(self, module, bucket_bytes=16 << 20, direct=False):
+    def __init__(self, module, bucket_bytes=16 << 20, direct=False, split_after=None):
         # direct=True: the libmpa backward kernels write parameter gradients straight into the flat
         # buckets (ops._direct) instead of handing tensors to autograd's AccumulateGrad -- valid when
         # every parameter is used once per step (true for the cls / part-seg models) and
@@ -95,11 +95,51 @@ class GradReducer:
         self.overlap = True          # False: no hook-launched collectives (HIP-graph replayed backward)
         self._where = {}
         self._handles = []
+        # split_after: a sub-module whose backward marks the point where the gradients of everything that ran
+        # AFTER it in the forward pass (itself included) are complete -- for the cls model `keepHigh.la4`: head,
+        # la5 and la4 hold 96 % of the gradient bytes and are done after the first quarter of the backward pass.
+        # Those parameters get their own bucket(s) (self.early), reduced while the rest of backward runs
+        # (on_split(), called from the module's backward hook).
+        self.split_after = split_after
+        self.early = []              # indices of the buckets that are complete at the split point
+        self.on_split = None         # callable run by the split module's backward hook (after the first build)
+        self._order, self._split_pos = [], None
+        self._order_hooks = []
+        if split_after is not None:
+            self._order_hooks = [p.register_post_accumulate_grad_hook(self._record_order) for p in self.params]
+            split_after.register_full_backward_hook(self._split_hook)
+
+    def _record_order(self, p):
+        if self.buckets is None:
+            self._order.append(p)
+
+    def _split_hook(self, module, grad_input, grad_output):
+        if self.buckets is None:
+            if self._split_pos is None:
+                self._split_pos = len(self._order)      # discovery pass: everything accumulated so far is "early"
+        elif self.on_split is not None:
+            self.on_split()
+
+    def start(self, which):
+        """Launch the all-reduce (sum) of the given buckets now (asynchronous; all_reduce() completes them)."""
+        if not is_dist():
+            return
+        for i in which:
+            b = self.buckets[i]
+            if not b.get("started"):
+                b["started"] = True
+                self._handles.append(dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, async_op=True))
 
     # -- bucket construction (after the first backward) --------------------------------------
     def _build(self):
+        for h in self._order_hooks:  # (discovery only: hooks keep AccumulateGrad nodes alive, see below)
+            h.remove()
+        self._order_hooks = []
         live = [p for p in self.params if p.grad is not None]
         live.reverse()               # roughly the order gradients become ready
+        early_set = None
+        if self.split_after is not None and self._split_pos is not None:
+            early_set = set(self._order[:self._split_pos])
         # parameter groups that a module wants back to back in the flat buffers (LocalTrans' k|v
         # projections are read as one stacked weight): a group is placed whole, in its own order
         group_of = {}
@@ -118,16 +158,23 @@ class GradReducer:
             units.append(unit)
             seen.update(unit)
         self.buckets = []
-        cur, cur_bytes = [], 0
-        for unit in units:
-            nbytes = sum(p.numel() * p.element_size() for p in unit)
-            if cur and cur_bytes + nbytes > self.bucket_bytes:
+        # a unit (parameters kept adjacent) is early only if all of it is
+        groups = [units] if early_set is None else [[u for u in units if all(p in early_set for p in u)],
+                                                    [u for u in units if not all(p in early_set for p in u)]]
+        for gi, group in enumerate(groups):
+            cur, cur_bytes = [], 0
+            first = len(self.buckets)
+            for unit in group:
+                nbytes = sum(p.numel() * p.element_size() for p in unit)
+                if cur and cur_bytes + nbytes > self.bucket_bytes:
+                    self._make_bucket(cur)
+                    cur, cur_bytes = [], 0
+                cur.extend(unit)
+                cur_bytes += nbytes
+            if cur:
                 self._make_bucket(cur)
-                cur, cur_bytes = [], 0
-            cur.extend(unit)
-            cur_bytes += nbytes
-        if cur:
-            self._make_bucket(cur)
+            if early_set is not None and gi == 0:
+                self.early = list(range(first, len(self.buckets)))
         # Hooks keep the AccumulateGrad nodes (and the stream they were created on) alive across
         # iterations; a HIP-graph captured backward must not inherit them (the accumulation would
         # fork onto the stale stream inside the capture), so they are only installed for overlap.
@@ -171,6 +218,7 @@ class GradReducer:
         for b in self.buckets:
             b["flat"].zero_()
             b["pending"] = len(b["params"])
+            b["started"] = False
             for p, v in zip(b["params"], b["views"]):
                 p.grad = v
 
@@ -184,7 +232,7 @@ class GradReducer:
                     dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM)
         else:
             for b in self.buckets:      # a bucket whose hook did not fire (or overlap is off)
-                if (b["pending"] != 0 or not self.overlap) and is_dist():
+                if (b["pending"] != 0 or not self.overlap) and is_dist() and not b.get("started"):
                     self._handles.append(dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, async_op=True))
             for h in self._handles:
                 h.wait()

@@ -108,7 +108,8 @@ class GraphedTrainStep:
     25.7 MB) -- a single ring all-reduce instead of two."""
 
     def __init__(self, model, loss_fn, example_batch, optimizer=None, lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
-                 weight_decay=0.0, warmup=2, bucket_bytes=64 << 20, compute_loss=None):
+                 weight_decay=0.0, warmup=2, bucket_bytes=64 << 20, compute_loss=None, split_after=None,
+                 capture_reduce=False):
         # compute_loss(model, loss_fn, *batch) -> scalar loss; default: loss_fn(model(batch[0]), *batch[1:])
         from .optim import FlatAdam
         self.model, self.loss_fn = model, loss_fn
@@ -116,8 +117,16 @@ class GraphedTrainStep:
         self.static = [t.clone() for t in example_batch]
         self.feeder = FpsStartFeeder()
         self.arena = ops.ZeroArena(self.static[0].device)       # the pass's pre-zeroed accumulators (one fill per step)
-        self.reducer = GradReducer(model, bucket_bytes=bucket_bytes, direct=True)
+        # split_after (a sub-module, e.g. model.keepHigh.la4): when its backward has run, the weight gradients queued so
+        # far (everything downstream of it in the forward pass: most of the gradient bytes) are flushed as an early
+        # grouped launch and sit complete in their own flat bucket(s).  capture_reduce=True additionally starts
+        # that bucket's all-reduce right there, INSIDE the captured graph (RCCL collectives are capturable), so it
+        # overlaps the rest of backward instead of running after the replay.
+        self.reducer = GradReducer(model, bucket_bytes=bucket_bytes, direct=True, split_after=split_after)
         self.reducer.overlap = False
+        self.capture_reduce = bool(capture_reduce) and is_dist() and world_size() > 1
+        if split_after is not None:
+            self.reducer.on_split = self._on_split
         ops.set_fps_start_hook(self.feeder)
 
         side = torch.cuda.Stream()
@@ -129,7 +138,8 @@ class GraphedTrainStep:
             self.opt.step()
             for _ in range(max(0, warmup - 1)):      # eager passes: warm allocator / workspaces
                 self._fwd_bwd()
-                self.reducer.all_reduce()
+                if not self.capture_reduce:          # (with capture_reduce the pass itself ends with the reduction)
+                    self.reducer.all_reduce()
                 self.opt.step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
@@ -142,6 +152,11 @@ class GraphedTrainStep:
         self.opt_graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.opt_graph):
             self.opt.step()
+
+    def _on_split(self):
+        ops.flush_weight_grads()                 # early grouped launch: the gradients of the early buckets are now complete
+        if self.capture_reduce:
+            self.reducer.start(self.reducer.early)
 
     def _fwd_bwd(self):
         self.feeder.begin_pass()
@@ -163,6 +178,8 @@ class GraphedTrainStep:
             ops.flush_weight_grads()          # ... and issued as one grouped launch
         finally:
             ops.defer_weight_grads(False)
+        if self.capture_reduce and self.reducer.buckets is not None:
+            self.reducer.all_reduce()         # the remaining buckets + completion of the early ones, inside the graph
         return loss
 
     def __call__(self, *batch):
@@ -171,7 +188,9 @@ class GraphedTrainStep:
                 dst.copy_(src, non_blocking=True)
         self.feeder.refill()
         self.graph.replay()
-        if is_dist() and world_size() > 1:
+        if is_dist() and world_size() > 1 and not self.capture_reduce:
+            if self.reducer.early:                                   # the early bucket(s) first: they are the bulk
+                self.reducer.start(self.reducer.early)
             self.reducer.all_reduce()
         if not _SKIP_OPT:
             sync = getattr(self.opt, "sync_hyper", None)

@@ -91,3 +91,48 @@ def test_shard_batch_partitions():
             assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))
             sizes = [b - a for a, b in parts]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _worker_split(rank, world, port, out):
+    """GradReducer(split_after=...): the buckets that are complete when the split module's backward has run are
+    reduced FROM ITS BACKWARD HOOK, overlapping the rest of backward; same result as one process."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import mpa_amd  # noqa: F401
+    from mpa_amd import distributed as md
+    md.init_process_group("gloo")
+    model = _make_model()
+    red = md.GradReducer(model, bucket_bytes=1 << 20, split_after=model.body[2])
+    red.overlap = False
+    fired = []
+    red.on_split = lambda: (fired.append(1), red.start(red.early))
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    x, y = _data()
+    lo, hi = md.shard_batch(x.shape[0])
+    for it in range(3):
+        red.zero_grad()
+        ((model(x[lo:hi]) - y[lo:hi]) ** 2).mean().backward()
+        red.all_reduce()
+        opt.step()
+    # body[2] and body[4] (weights + biases) are complete when body[2]'s backward has run; body[0] is not
+    early = {id(p) for i in red.early for p in red.buckets[i]["params"]}
+    assert early == {id(p) for m in (model.body[2], model.body[4]) for p in m.parameters()}
+    assert len(red.buckets) == 2 and len(fired) == 2        # the hook launches reductions from the second pass on
+    if rank == 0:
+        torch.save({k: v.clone() for k, v in model.state_dict().items()}, out)
+    md.barrier()
+    md.shutdown()
+
+
+def test_split_reducer_overlaps_and_matches_single_process(tmp_path):
+    world, port, out = 2, _free_port(), str(tmp_path / "dp_split.pt")
+    mp.spawn(_worker_split, args=(world, port, out), nprocs=world, join=True)
+    dp = torch.load(out, weights_only=True)
+    model = _make_model()
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    x, y = _data()
+    for _ in range(3):
+        opt.zero_grad()
+        ((model(x) - y) ** 2).mean().backward()
+        opt.step()
+    for k, v in model.state_dict().items():
+        assert torch.allclose(v, dp[k], atol=1e-6), k
