@@ -204,6 +204,7 @@ def main():
     ap.add_argument("--config", choices=sorted(CONFIGS), default="cls-fp32")
     ap.add_argument("--batch", type=int, default=0, help="clouds per GPU (default: the configuration's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-forward-only", action="store_true", help="skip the secondary forward-only leg (profiling runs)")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python (no HIP graph)")
     a = ap.parse_args()
     task, dt, npoint, dbatch, which = CONFIGS[a.config]
@@ -374,7 +375,7 @@ def main():
             "roofline": roof,
             "roofline_other_kernels": kernels[1:],
         }
-        if world == 1 and not a.eager:
+        if world == 1 and not a.eager and not a.no_forward_only:
             line["forward_only"] = forward_only(run_forward, graphed.feeder, graphed.arena, batch)
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(task, batch if task == "cls" else min(batch, 4), npoint,

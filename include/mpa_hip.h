@@ -164,6 +164,21 @@ int mpa_gemm_f32(const float *A, int lda, int transA, const float *B, int ldb, i
                  const float *bias, float *C, int ldc, int M, int N, int K, int accumulate,
                  float *tile_stats, int stats_replicas, float *a_col_sum, float *workspace, size_t workspace_bytes,
                  void *stream);
+/* Grouped forward / dX products: `count` (<= 8) INDEPENDENT  C_p[M,N] = A_p[M,K] op(B_p) (+ bias_p)  in one launch
+ * (the Linear units of LocalMerge's parallel attention streams, modules/pointnet2_utils.py:465-470, and of Fuse's
+ * four source states, :617-705: small problems that each leave the chip half empty).  All problems share transB;
+ * tile_stats / stats_replicas as in mpa_gemm_f32 (accumulate form only when stats_replicas > 0).  No split-K.
+ * `problems` is a HOST array (copied into the kernel arguments).  The _bf16 form takes bf16 A and C (B bf16 or
+ * fp32 as b_is_f32 says). */
+typedef struct MpaGemmProblem {
+    const void *A;
+    const void *B;
+    const float *bias;
+    void *C;
+    float *tile_stats;
+    int lda, ldb, ldc, M, N, K, stats_replicas;
+} MpaGemmProblem;
+int mpa_gemm_grouped_f32(const MpaGemmProblem *problems, int count, int transB, void *stream);
 /* Grouped weight gradients: out_p[M,N] = A_p^T B_p for `count` independent problems in one launch
  * (+ one reduce launch), A_p stored [K][M] (lda), B_p stored [K][N] (ldb): dW = dY^T X of every
  * Linear of a backward pass.  Each is a latency-bound stream with a tiny output, so they are
@@ -366,6 +381,7 @@ int mpa_upsample_mean_bwd_bf16(const mpa_bf16 *grad_out, const int64_t *knn_idx,
                                int B, int S, int K, int Nf, int C, mpa_bf16 *grad_points,
                                void *stream);
 int mpa_group_col_sum_bf16(const mpa_bf16 *x, int G, int R, int C, int ld, float *out, void *stream);
+int mpa_gemm_grouped_bf16(const MpaGemmProblem *problems, int count, int transB, int b_is_f32, void *stream);
 /*BF16_MORE*/
 
 #ifdef __cplusplus

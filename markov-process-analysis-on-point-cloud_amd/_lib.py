@@ -69,6 +69,15 @@ class GemmTnProblem(ctypes.Structure):
 SIGNATURES["mpa_gemm_tn_grouped_f32"] = [ctypes.POINTER(GemmTnProblem), _i, _vp, ctypes.c_size_t, _vp]
 
 
+class GemmProblem(ctypes.Structure):
+    """struct MpaGemmProblem of include/mpa_hip.h"""
+    _fields_ = [("A", _vp), ("B", _vp), ("bias", _vp), ("C", _vp), ("tile_stats", _vp),
+                ("lda", _i), ("ldb", _i), ("ldc", _i), ("M", _i), ("N", _i), ("K", _i), ("stats_replicas", _i)]
+
+
+SIGNATURES["mpa_gemm_grouped_f32"] = [ctypes.POINTER(GemmProblem), _i, _i, _vp]
+
+
 class GemmTnProblemBf16(ctypes.Structure):
     """struct MpaGemmTnProblemBf16 of include/mpa_hip.h"""
     _fields_ = [("A", _vp), ("B", _vp), ("out", _vp), ("a_col_sum", _vp),
@@ -80,6 +89,7 @@ SIGNATURES.update({
     "mpa_gemm_bf16": [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp],
     "mpa_bn_stats_act_fwd_bf16": SIGNATURES["mpa_bn_stats_act_fwd_f32"],
     "mpa_gemm_tn_grouped_bf16": [ctypes.POINTER(GemmTnProblemBf16), _i, _vp, ctypes.c_size_t, _vp],
+    "mpa_gemm_grouped_bf16": [ctypes.POINTER(GemmProblem), _i, _i, _i, _vp],
     "mpa_bn_act_fwd_bf16": SIGNATURES["mpa_bn_act_fwd_f32"],
     "mpa_bn_act_bwd_reduce_bf16": SIGNATURES["mpa_bn_act_bwd_reduce_f32"],
     "mpa_bn_act_bwd_apply_bf16": SIGNATURES["mpa_bn_act_bwd_apply_f32"],

@@ -490,6 +490,39 @@ __global__ __launch_bounds__(NT, 2) void gemm_tn_grouped_kernel(const GroupedArg
                                vecB, nullptr, nullptr, q.a_col_sum, q.stream);
 }
 
+// ---- grouped forward / dX products: a few INDEPENDENT  C_p = A_p op(B_p) (+ bias)  in one launch -- the Linear units
+// of LocalMerge's parallel attention streams (ffn | ffn, conv_res | conv_res) and of Fuse's four source
+// states.  Each is a ~1 GFLOP problem of 256-512 tiles that leaves the chip half empty and pays its own ramp-up
+// and tail; together their phases overlap.  Same tile body as gemm_kernel (no split-K: the group is the
+// parallelism); descriptors travel in the kernel arguments.
+constexpr int GROUP_NT_MAX = 8;
+struct NtProblem {
+    const float *A, *B, *bias;
+    float *C, *stats;
+    int lda, ldb, ldc, M, N, K, tiles, stats_acc, vec;
+};
+struct NtArgs {
+    int count;
+    int block_start[GROUP_NT_MAX + 1];
+    NtProblem p[GROUP_NT_MAX];
+};
+
+template <bool TB>
+__global__ __launch_bounds__(NT, 2) void gemm_nt_grouped_kernel(const NtArgs args)
+{
+    __shared__ int which;
+    if (threadIdx.x == 0) {
+        int b = blockIdx.x, i = 0;
+        while (i + 1 < args.count && b >= args.block_start[i + 1]) ++i;
+        which = i;
+    }
+    __syncthreads();
+    const NtProblem &q = args.p[which];
+    const int kchunk = ((q.K + KS - 1) / KS) * KS;
+    gemm_body<false, TB>(blockIdx.x - args.block_start[which], 0, q.A, q.lda, q.B, q.ldb, q.bias, q.C, q.ldc, q.M, q.N, q.K,
+                         kchunk, 0, q.vec & 1, (q.vec >> 1) & 1, q.stats, nullptr, nullptr, 0, q.stats_acc);
+}
+
 // ---- short-K products (K = 64 or 128, whole tiles): the layers of the fine point-set states,
 // M = B*S up to 65536 rows against 64..256 channels.  They are HBM-bound (16 FLOP/B) and, in the
 // general kernel above, latency-bound: one slab means no pipelining inside a workgroup, and its
@@ -1593,4 +1626,37 @@ extern "C" int mpa_bn_stats_act_fwd_bf16(const mpa_bf16 *x, const float *stats, 
                                         running_var, training, momentum, eps, num_batches_tracked, gamma, beta,
                                         reinterpret_cast<const bf16_t *>(residual), slope, reinterpret_cast<bf16_t *>(y),
                                         save_mean_invstd, stream);
+}
+
+extern "C" int mpa_gemm_grouped_f32(const MpaGemmProblem *problems, int count, int transB, void *stream)
+{
+    MPA_CLEAR_ERROR();
+    if (!problems || count <= 0 || count > GROUP_NT_MAX) return MPA_EINVAL;
+    NtArgs ga;
+    int blocks = 0;
+    ga.block_start[0] = 0;
+    for (int i = 0; i < count; ++i) {
+        const MpaGemmProblem &in = problems[i];
+        if (!in.A || !in.B || !in.C || in.M <= 0 || in.N <= 0 || in.K <= 0 || in.lda < in.K || in.ldc < in.N ||
+            in.ldb < (transB ? in.K : in.N))
+            return MPA_EINVAL;
+        NtProblem &q = ga.p[i];
+        q.A = reinterpret_cast<const float *>(in.A); q.B = reinterpret_cast<const float *>(in.B); q.bias = in.bias;
+        q.C = reinterpret_cast<float *>(in.C); q.stats = in.tile_stats;
+        q.lda = in.lda; q.ldb = in.ldb; q.ldc = in.ldc; q.M = in.M; q.N = in.N; q.K = in.K;
+        q.stats_acc = in.stats_replicas;
+        q.tiles = mpa_ceil_div(in.M, TS) * mpa_ceil_div(in.N, TS);
+        q.vec = ((reinterpret_cast<uintptr_t>(in.A) & 15) == 0 && (in.lda % 4) == 0 ? 1 : 0) |
+                ((reinterpret_cast<uintptr_t>(in.B) & 15) == 0 && (in.ldb % 4) == 0 ? 2 : 0);
+        blocks += q.tiles;
+        ga.block_start[i + 1] = blocks;
+    }
+    ga.count = count;
+    constexpr size_t lds = gemm_lds_bytes(false, true);
+    if (transB)
+        hipLaunchKernelGGL(gemm_nt_grouped_kernel<true>, dim3(blocks), dim3(NT), lds, (hipStream_t)stream, ga);
+    else
+        hipLaunchKernelGGL(gemm_nt_grouped_kernel<false>, dim3(blocks), dim3(NT), lds, (hipStream_t)stream, ga);
+    MPA_LAUNCH_CHECK();
+    return MPA_OK;
 }

@@ -208,14 +208,13 @@ __device__ __forceinline__ void gemm_main_loop(const bf16_t *__restrict__ A, int
 }
 
 template <bool TB, int BN, typename TBm, bool OUT_F32>
-__global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const bf16_t *__restrict__ A, int lda,
-                                                          const TBm *__restrict__ Bm, int ldb,
-                                                          const float *__restrict__ bias, void *__restrict__ Cv, int ldc,
-                                                          int M, int N, int K, float *__restrict__ tile_stats,
-                                                          int stats_acc, int vecA, int vecB, int vecC)
+__device__ __forceinline__ void gemm_bf16_body(const int block_id, const bf16_t *__restrict__ A, int lda,
+                                               const TBm *__restrict__ Bm, int ldb, const float *__restrict__ bias,
+                                               void *__restrict__ Cv, int ldc, int M, int N, int K,
+                                               float *__restrict__ tile_stats, int stats_acc, int vecA, int vecB,
+                                               int vecC, char *smem)
 {
     constexpr int NJ = GemmCfg<BN>::NJ;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, r31 = lane & 31;
@@ -223,7 +222,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const bf16_t *__restri
 
     const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
     const int ntiles = tiles_m * tiles_n;
-    int id = blockIdx.x;
+    int id = block_id;
     if ((ntiles & 7) == 0) id = (id & 7) * (ntiles >> 3) + (id >> 3);       // XCD-aware: an XCD gets a run of tiles
     const int m0 = (id / tiles_n) * BM, n0 = (id % tiles_n) * BN;
 
@@ -338,6 +337,47 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const bf16_t *__restri
             }
         }
     }
+}
+
+template <bool TB, int BN, typename TBm, bool OUT_F32>
+__global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const bf16_t *__restrict__ A, int lda,
+                                                          const TBm *__restrict__ Bm, int ldb,
+                                                          const float *__restrict__ bias, void *__restrict__ Cv, int ldc,
+                                                          int M, int N, int K, float *__restrict__ tile_stats,
+                                                          int stats_acc, int vecA, int vecB, int vecC)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    gemm_bf16_body<TB, BN, TBm, OUT_F32>(blockIdx.x, A, lda, Bm, ldb, bias, Cv, ldc, M, N, K, tile_stats, stats_acc, vecA,
+                                         vecB, vecC, smem);
+}
+
+// ---- grouped forward / dX products: a few independent problems in one launch (the Linear units of parallel
+// attention streams, Fuse's four source states): see gemm_nt_grouped_kernel in linear.hip.
+constexpr int GROUP_NT_MAX = 8;
+struct NtProblemB {
+    const bf16_t *A;
+    const void *B;
+    const float *bias;
+    void *C;
+    float *stats;
+    int lda, ldb, ldc, M, N, K, stats_acc, vec;
+};
+struct NtArgsB {
+    int count;
+    int block_start[GROUP_NT_MAX + 1];
+    NtProblemB p[GROUP_NT_MAX];
+};
+
+template <bool TB, int BN, typename TBm>
+__global__ __launch_bounds__(NT, 2) void gemm_bf16_grouped_kernel(const NtArgsB args)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int which = 0;
+    while (which + 1 < args.count && (int)blockIdx.x >= args.block_start[which + 1]) ++which;     // (wave-uniform)
+    const NtProblemB &q = args.p[which];
+    gemm_bf16_body<TB, BN, TBm, false>(blockIdx.x - args.block_start[which], q.A, q.lda,
+                                       reinterpret_cast<const TBm *>(q.B), q.ldb, q.bias, q.C, q.ldc, q.M, q.N, q.K, q.stats,
+                                       q.stats_acc, q.vec & 1, (q.vec >> 1) & 1, (q.vec >> 2) & 1, smem);
 }
 
 template <int BN> constexpr size_t gemm_bf16_lds()
@@ -602,6 +642,73 @@ extern "C" int mpa_gemm_tn_grouped_bf16(const MpaGemmTnProblemBf16 *problems, in
         hipLaunchKernelGGL(gemm_bf16_tn_grouped_kernel, dim3(blocks), dim3(NT), 0, st, ga);
         if (nr > 0) hipLaunchKernelGGL(splitk_reduce_grouped_kernel, dim3(rblocks), dim3(256), 0, st, ra);
     }
+    MPA_LAUNCH_CHECK();
+    return MPA_OK;
+}
+
+template <bool TB, int BN, typename TBm>
+static int launch_grouped_bf16(const NtArgsB &ga, int blocks, hipStream_t st)
+{
+    constexpr size_t lds = gemm_bf16_lds<BN>();
+    auto kern = gemm_bf16_grouped_kernel<TB, BN, TBm>;
+    if (lds > 64 * 1024) {
+        static bool once = false;
+        if (!once) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds) != hipSuccess)
+                return MPA_EHIP;
+            once = true;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(NT), lds, st, ga);
+    return MPA_OK;
+}
+
+extern "C" int mpa_gemm_grouped_bf16(const MpaGemmProblem *problems, int count, int transB, int b_is_f32, void *stream)
+{
+    MPA_CLEAR_ERROR();
+    if (!problems || count <= 0 || count > GROUP_NT_MAX) return MPA_EINVAL;
+    // one tile width for the whole launch: 128 columns when every problem is a multiple of it and the grid is large
+    long long t128 = 0;
+    bool all128 = true;
+    for (int i = 0; i < count; ++i) {
+        const MpaGemmProblem &in = problems[i];
+        if (!in.A || !in.B || !in.C || in.M <= 0 || in.N <= 0 || in.K <= 0 || in.lda < in.K || in.ldc < in.N ||
+            in.ldb < (transB ? in.K : in.N))
+            return MPA_EINVAL;
+        all128 = all128 && (in.N % 128 == 0);
+        t128 += (long long)mpa_ceil_div(in.M, BM) * mpa_ceil_div(in.N, 128);
+    }
+    const int bn = (all128 && t128 >= 192) ? 128 : 64;
+    NtArgsB ga;
+    int blocks = 0;
+    ga.block_start[0] = 0;
+    for (int i = 0; i < count; ++i) {
+        const MpaGemmProblem &in = problems[i];
+        NtProblemB &q = ga.p[i];
+        q.A = reinterpret_cast<const bf16_t *>(in.A); q.B = in.B; q.bias = in.bias; q.C = in.C; q.stats = in.tile_stats;
+        q.lda = in.lda; q.ldb = in.ldb; q.ldc = in.ldc; q.M = in.M; q.N = in.N; q.K = in.K;
+        q.stats_acc = in.stats_replicas;
+        const int vecA = ((reinterpret_cast<uintptr_t>(in.A) & 15) == 0) && (in.lda % 8 == 0);
+        const int vecB = ((reinterpret_cast<uintptr_t>(in.B) & 15) == 0) && (in.ldb % (b_is_f32 ? 4 : 8) == 0);
+        const int vecC = ((reinterpret_cast<uintptr_t>(in.C) & 15) == 0) && (in.ldc % 8 == 0);
+        q.vec = vecA | (vecB << 1) | (vecC << 2);
+        blocks += mpa_ceil_div(in.M, BM) * mpa_ceil_div(in.N, bn);
+        ga.block_start[i + 1] = blocks;
+    }
+    ga.count = count;
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+#define MPA_GRP(TB_, BN_, T_) rc = launch_grouped_bf16<TB_, BN_, T_>(ga, blocks, st)
+    if (transB) {
+        if (b_is_f32) { if (bn == 128) MPA_GRP(true, 128, float); else MPA_GRP(true, 64, float); }
+        else { if (bn == 128) MPA_GRP(true, 128, bf16_t); else MPA_GRP(true, 64, bf16_t); }
+    } else {
+        if (b_is_f32) { if (bn == 128) MPA_GRP(false, 128, float); else MPA_GRP(false, 64, float); }
+        else { if (bn == 128) MPA_GRP(false, 128, bf16_t); else MPA_GRP(false, 64, bf16_t); }
+    }
+#undef MPA_GRP
+    if (rc != MPA_OK) return rc;
     MPA_LAUNCH_CHECK();
     return MPA_OK;
 }

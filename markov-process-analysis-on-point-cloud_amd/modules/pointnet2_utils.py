@@ -253,7 +253,32 @@ def local_trans_pair(t1, t2, features, idx1, idx2, center):
     qq = ops.linear_stack(center, (t1.q, t2.q), (True, True))
     kvkv = ops.linear_stack(features, (t1.k, t1.v, t2.k, t2.v), (True, False, True, False))
     c1, c2 = ops.diffattn_pair(qq, kvkv, idx1, idx2)
-    return t1.finish(c1, center), t2.finish(c2, center)
+    return finish_group((t1, t2), (c1, c2), (center, center))
+
+
+def _unit_group(units, xs, residuals=None, chain=False):
+    """[unit(x)] for independent `Linear` units (BatchNorm form) through ops.linear_bn_act_group: their forward
+    products are one launch and their input-gradient products another."""
+    if any(u.bn_flag for u in units):                          # LayerNorm form (never built by the models)
+        outs = [u.fused(x, None if residuals is None else residuals[i]) for i, (u, x) in enumerate(zip(units, xs))]
+        return outs
+    return ops.linear_bn_act_group(list(xs), [u.linear for u in units], [u.norm2 for u in units],
+                                   [0.2 if u.act_flag else None for u in units], residuals=residuals, chain=chain)
+
+
+def finish_group(trans, contexts, centers):
+    """[t.finish(context, centre)] for parallel LocalTrans streams: the conv_res units of the streams that have one
+    run as a group, then the ffn units (each with its stream's residual)."""
+    res = list(centers)
+    by_dtype = {}
+    for i, t in enumerate(trans):
+        if t.residual:
+            by_dtype.setdefault(centers[i].dtype, []).append(i)          # (the xyz stream's centres stay fp32)
+    for members in by_dtype.values():
+        outs = _unit_group([trans[i].conv_res for i in members], [centers[i] for i in members])
+        for i, o in zip(members, outs):
+            res[i] = o
+    return _unit_group([t.ffn for t in trans], list(contexts), residuals=res)
 
 
 class LocalMerge(nn.Module):
@@ -283,12 +308,27 @@ class LocalMerge(nn.Module):
         else:
             fs = feature if FPS_idx is None else index_points(feature, FPS_idx)
             _, idx_feature = knn_point(self.knn, feature, fs)
-            xyz_f = self.xyz_Trans(features=base_xyz, idx=idx, pos=base_xyz, FPS_idx=FPS_idx, xyz=True)
-            f1, f2 = local_trans_pair(self.feature_Trans1, self.feature_Trans2, feature, idx, idx_feature, fs)
+            xyz_f, f1, f2 = self._three_streams(base_xyz, feature, idx, idx_feature, FPS_idx, fs)
             merge_features = self.fc2(torch.cat((xyz_f, f1, f2), dim=2))
         if FPS_idx is not None:
             normal = index_points(normal, FPS_idx)
         return merge_features, normal, idx, dist
+
+    def _three_streams(self, base_xyz, feature, idx, idx_feature, FPS_idx, fs):
+        """xyz_Trans(base_xyz, idx), feature_Trans1(feature, idx), feature_Trans2(feature, idx_feature): the
+        attention contexts per stream as before, their closing conv_res / ffn units as groups."""
+        tx, t1, t2 = self.xyz_Trans, self.feature_Trans1, self.feature_Trans2
+        if tx.usetanh or t1.usetanh or t2.usetanh:
+            xyz_f = tx(features=base_xyz, idx=idx, pos=base_xyz, FPS_idx=FPS_idx, xyz=True)
+            f1, f2 = local_trans_pair(t1, t2, feature, idx, idx_feature, fs)
+            return xyz_f, f1, f2
+        cx = index_points(base_xyz, FPS_idx) if FPS_idx is not None else base_xyz
+        ctx_x = ops.diffattn_xyz(base_xyz, cx, idx, tx.q.weight, tx.q.bias, tx.k.weight, tx.k.bias, tx.v.weight,
+                                 tx.v.bias)
+        qq = ops.linear_stack(fs, (t1.q, t2.q), (True, True))
+        kvkv = ops.linear_stack(feature, (t1.k, t1.v, t2.k, t2.v), (True, False, True, False))
+        c1, c2 = ops.diffattn_pair(qq, kvkv, idx, idx_feature)
+        return finish_group((tx, t1, t2), (ctx_x, c1, c2), (cx, fs, fs))
 
 
 def _compose(*maps):
@@ -324,11 +364,11 @@ class Fuse(nn.Module):
         knn = [knn_0, knn_1, knn_2, knn_3, knn_4]
         xyz = [xyz0, xyz1, xyz2, xyz3, xyz4]
         dst = [t.shape[1] for t in f].index(num_point)
-        acc = f[dst]
+        convs, ts = [], []
         for src in range(5):
             if src == dst:
                 continue
-            conv = getattr(self, "conv%d%d" % (src, dst))
+            convs.append(getattr(self, "conv%d%d" % (src, dst)))
             if src < dst:      # finer -> coarser: gather through the composed FPS maps
                 t = index_points(f[src], _compose(*fps[src:dst]))
             elif src == dst + 1:   # adjacent coarser state: reuse the encoder's kNN
@@ -336,7 +376,15 @@ class Fuse(nn.Module):
             else:              # non-adjacent: fresh xyz kNN of the coarse state in the target state
                 ratio = f[dst].shape[1] // f[src].shape[1]
                 t = upsample(f[src], knn_point(self.knn, xyz[dst], xyz[src])[1], scale_ratio=ratio)
-            acc = acc + conv(t)
+            ts.append(t)
+        # acc = f[dst] + conv_0(t_0) + conv_1(t_1) + ... (same order of additions as the reference's expression):
+        # the four products are one grouped launch, every unit's normalise pass adds the running sum as its residual
+        if any(c.bn_flag for c in convs):
+            acc = f[dst]
+            for c, t in zip(convs, ts):
+                acc = acc + c(t)
+        else:
+            acc = _unit_group(convs, ts, residuals=[f[dst]] + [None] * (len(convs) - 1), chain=True)
         f[dst] = getattr(self, "conv%d" % dst).fused(acc, f[dst])
         return tuple(f)
 

@@ -12,7 +12,7 @@ import os
 
 import torch
 
-from ._lib import lib, check, GemmTnProblem, GemmTnProblemBf16
+from ._lib import lib, check, GemmProblem, GemmTnProblem, GemmTnProblemBf16
 
 _vp = ctypes.c_void_p
 
@@ -735,6 +735,42 @@ def _weight_grads_bf16(queue):
             algo_flops=sum(2 * q[5] * q[6] * q[7] for q in queue))
 
 
+def _gemm_group(problems, tB):
+    """Independent forward / dX products C = A op(B) (+ bias) as ONE launch (mpa_gemm_grouped_*): problems =
+    [(A, lda, B, ldb, bias, C, ldc, M, N, K, tile_stats, stats_acc)].  fp32 problems that the short-K kernel
+    takes (whole 64x64 tiles, K = 64 / 128: the fine states' layers, already at their HBM rate) keep their own
+    launches; a single problem is a plain _gemm."""
+    if not problems:
+        return
+    bf16 = problems[0][0].dtype == torch.bfloat16
+
+    def shortk(q):
+        A, lda, Bm, ldb, bias, C, ldc, M, N, K = q[:10]
+        return (M % 64 == 0 and N % 64 == 0 and K in (64, 128) and lda % 4 == 0 and ldb % 4 == 0
+                and A.data_ptr() % 16 == 0 and Bm.data_ptr() % 16 == 0)
+
+    if len(problems) == 1 or len(problems) > 8 or (not bf16 and all(shortk(q) for q in problems)):
+        for A, lda, Bm, ldb, bias, C, ldc, M, N, K, stats, acc in problems:
+            _gemm(A, lda, 0, Bm, ldb, tB, bias, C, ldc, M, N, K, 0, stats, stats_acc=acc)
+        return
+    n = len(problems)
+    arr = (GemmProblem * n)()
+    for i, (A, lda, Bm, ldb, bias, C, ldc, M, N, K, stats, acc) in enumerate(problems):
+        arr[i].A, arr[i].B, arr[i].C = A.data_ptr(), Bm.data_ptr(), C.data_ptr()
+        arr[i].bias = bias.data_ptr() if bias is not None else None
+        arr[i].tile_stats = stats.data_ptr() if stats is not None else None
+        arr[i].lda, arr[i].ldb, arr[i].ldc, arr[i].M, arr[i].N, arr[i].K = lda, ldb, ldc, M, N, K
+        arr[i].stats_replicas = acc
+    flops = sum(2 * q[7] * q[8] * q[9] for q in problems)
+    if bf16:
+        b32 = problems[0][2].dtype == torch.float32
+        _launch("mpa_gemm_grouped_bf16", arr, n, 1 if tB else 0, int(b32), _stream(), algo_flops=flops,
+                algo_bytes=sum(2 * q[7] * q[9] + (4 if b32 else 2) * q[8] * q[9] + 2 * q[7] * q[8] for q in problems))
+    else:
+        _launch("mpa_gemm_grouped_f32", arr, n, 1 if tB else 0, _stream(), algo_flops=flops,
+                algo_bytes=sum(4 * (q[7] * q[9] + q[8] * q[9] + q[7] * q[8]) for q in problems))
+
+
 _ZEROS = {}
 
 
@@ -1178,6 +1214,146 @@ class _LinearBNAct(torch.autograd.Function):
         gbeta = None if dbeta is not None else gb_
         gres = gout if has_res else None
         return gx, gW, gb, ggamma, gbeta, None, None, None, gres, None, None, None, None
+
+
+class _LinearBNActGroup(torch.autograd.Function):
+    """n INDEPENDENT Linear -> BatchNorm1d -> LeakyReLU (+ residual) units in one autograd node: their forward
+    products are one grouped launch, their dX products another (the units of LocalMerge's parallel attention
+    streams and of Fuse's four source states are ~1 GFLOP each: alone they leave the chip half empty).
+    chain=True: unit i's residual is unit i-1's output (unit 0's is the given one) and only the last output is
+    returned -- acc + sum_i unit_i(x_i), Fuse's accumulation, without the separate additions.
+    ts: 9 tensors per unit -- x [M,K], W, b, gamma, beta, running_mean, running_var, num_batches_tracked, residual."""
+
+    @staticmethod
+    def forward(ctx, cfg, *ts):
+        units_cfg, chain = cfg
+        n = len(units_cfg)
+        U = [ts[9 * i:9 * i + 9] for i in range(n)]
+        dev = U[0][0].device
+        ys, stats, Rs = [], [], []
+        probs = []
+        for (training, momentum, eps, slope), (x, W, b, gamma, beta, rm, rv, nbt, res) in zip(units_cfg, U):
+            M, K = x.shape
+            N = W.shape[0]
+            y = torch.empty(M, N, dtype=x.dtype, device=dev)
+            R = 8 if (M + 63) // 64 >= 256 else 1
+            st = _zeros_acc(R * 3 * N, dev) if training else None
+            probs.append((x, K, W, K, b, y, N, M, N, K, st, R if training else 0))
+            ys.append(y); stats.append(st); Rs.append(R)
+        _gemm_group(probs, 1)
+        outs, saved_all, sums_all = [], [], []
+        prev = None
+        for i, ((training, momentum, eps, slope), (x, W, b, gamma, beta, rm, rv, nbt, res)) in enumerate(zip(units_cfg, U)):
+            M, N = ys[i].shape
+            out = torch.empty(M, N, dtype=x.dtype, device=dev)
+            saved = torch.empty(2, N, dtype=torch.float32, device=dev)
+            sums = _zeros_acc(_BN_REPLICAS * 2 * N, dev).view(_BN_REPLICAS, 2, N)
+            r = (prev if (chain and i > 0) else res)
+            _launch("mpa_bn_stats_act_fwd_" + _sfx(ys[i]), _p(ys[i]), _p(stats[i]), Rs[i], M, N, _p(rm), _p(rv), int(training),
+                    float(momentum), float(eps), _p(nbt), _p(gamma), _p(beta), _p(r), float(slope), _p(out), _p(saved),
+                    _stream())
+            outs.append(out); saved_all.append(saved); sums_all.append(sums)
+            prev = out
+        keep = []
+        for i, (x, W, b, gamma, beta, rm, rv, nbt, res) in enumerate(U):
+            keep += [x, W, ys[i], gamma, beta, saved_all[i], sums_all[i]]
+        ctx.save_for_backward(*keep)
+        ctx.cfg = (units_cfg, chain, [u[2] is not None for u in U], [u[8] is not None for u in U])
+        ctx.direct = [(_direct(u[1]), _direct(u[2]), _direct(u[3]), _direct(u[4])) for u in U]
+        ctx.ran_backward = False
+        return outs[-1] if chain else tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        units_cfg, chain, has_bias, has_res = ctx.cfg
+        n = len(units_cfg)
+        S = ctx.saved_tensors
+        dev = S[0].device
+        if ctx.ran_backward:
+            raise RuntimeError("_LinearBNActGroup: a second backward through the same node is not supported")
+        ctx.ran_backward = True
+        gys, probs, gxs = [], [], [None] * n
+        for i in range(n):
+            x, W, y, gamma, beta, saved, sums = S[7 * i:7 * i + 7]
+            training, momentum, eps, slope = units_cfg[i]
+            M, K = x.shape
+            N = W.shape[0]
+            gout, ldg = _rows_ld(gouts[0] if chain else gouts[i])
+            dW, db, dgamma, dbeta = ctx.direct[i]
+            _launch("mpa_bn_act_bwd_reduce_" + _sfx(y), _p(y), _p(gout), _p(saved[0]), _p(saved[1]), _p(gamma), _p(beta), slope,
+                    M, N, ldg, _p(sums), _BN_REPLICAS, _stream())
+            gy = torch.empty(M, N, dtype=y.dtype, device=dev)
+            gg = dgamma if dgamma is not None else torch.empty(N, dtype=torch.float32, device=dev)
+            gb_ = dbeta if dbeta is not None else torch.empty(N, dtype=torch.float32, device=dev)
+            _launch("mpa_bn_act_bwd_apply_" + _sfx(y), _p(y), _p(gout), _p(saved[0]), _p(saved[1]), _p(gamma), _p(beta),
+                    _p(sums), _BN_REPLICAS, slope, int(training), M, N, ldg, _p(gy), _p(gg), _p(gb_), _stream())
+            gys.append((gy, gg, gb_))
+            if ctx.needs_input_grad[1 + 9 * i]:
+                gx = torch.empty(M, K, dtype=x.dtype, device=dev)
+                gxs[i] = gx
+                probs.append((gy, N, W, K, None, gx, K, M, K, N, None, 0))
+        _gemm_group(probs, 0)                                     # dX_i = gy_i W_i: one launch
+        grads = []
+        for i in range(n):
+            x, W, y, gamma, beta, saved, sums = S[7 * i:7 * i + 7]
+            training = units_cfg[i][0]
+            M, K = x.shape
+            N = W.shape[0]
+            gy, gg, gb_ = gys[i]
+            dW, db, dgamma, dbeta = ctx.direct[i]
+            gW = gb = None
+            if ctx.needs_input_grad[1 + 9 * i + 1]:
+                gW = dW if dW is not None else torch.empty(N, K, dtype=torch.float32, device=dev)
+                _weight_grad(gy, N, x, K, gW, N, K, M, direct=dW is not None)
+                if dW is not None:
+                    gW = None
+            if has_bias[i] and ctx.needs_input_grad[1 + 9 * i + 2]:
+                if training:                       # identically zero in front of a train-mode BatchNorm (see _LinearBNAct)
+                    gb = None if db is not None else _zeros_like_cached(dev, N)
+                elif db is not None:
+                    _col_sum_into(gy, db)
+                else:
+                    gb = _col_sum(gy)
+            gout = gouts[0] if chain else gouts[i]
+            gres = gout if (has_res[i] and (not chain or i == 0)) else None
+            grads += [gxs[i], gW, gb, None if dgamma is not None else gg, None if dbeta is not None else gb_, None, None,
+                      None, gres]
+        return (None,) + tuple(grads)
+
+
+def linear_bn_act_group(xs, linears, bns, slopes, residuals=None, chain=False):
+    """[unit_i(x_i)] for n independent Linear units (nn.Linear `linears[i]`, nn.BatchNorm1d `bns[i]`, LeakyReLU slope
+    or None) with optional residuals -- see _LinearBNActGroup.  chain=True returns residuals[0] + sum_i unit_i(x_i)."""
+    n = len(xs)
+    residuals = residuals or [None] * n
+    if DETERMINISTIC_BN or n == 1:
+        outs, acc = [], residuals[0]
+        for i in range(n):
+            o = linear_bn_act(xs[i], linears[i].weight, linears[i].bias, bns[i], slopes[i],
+                              residual=(acc if chain else residuals[i]))
+            outs.append(o)
+            acc = o
+        return outs[-1] if chain else outs
+    _dev(*xs)
+    lead = [x.shape[:-1] for x in xs]
+    cfg, ts = [], []
+    for i in range(n):
+        bn = bns[i]
+        training = bn.training or bn.running_mean is None
+        x2 = _feat(xs[i]).reshape(-1, xs[i].shape[-1])
+        if training and x2.shape[0] <= 1:
+            raise ValueError("Expected more than 1 value per channel when training (BatchNorm1d)")
+        W = linears[i].weight
+        res = residuals[i] if (not chain or i == 0) else None
+        res2 = None if res is None else _feat(res).to(x2.dtype).reshape(-1, W.shape[0])
+        cfg.append((bool(training), 0.1 if bn.momentum is None else bn.momentum, bn.eps,
+                    1.0 if slopes[i] is None else slopes[i]))
+        ts += [x2, _f32(W), linears[i].bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+               bn.num_batches_tracked if training else None, res2]
+    out = _LinearBNActGroup.apply((tuple(cfg), bool(chain)), *ts)
+    if chain:
+        return out.view(*lead[-1], linears[-1].weight.shape[0])
+    return [o.view(*lead[i], linears[i].weight.shape[0]) for i, o in enumerate(out)]
 
 
 def linear_bn_act(x, weight, bias, bn, slope, residual=None):

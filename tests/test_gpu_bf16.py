@@ -429,3 +429,49 @@ def test_graphed_partseg_step_bf16_replays_stay_finite():
             assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
         finally:
             step.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("specs,M,chain", [
+    (((64, 128, True), (64, 128, True), (64, 128, True)), 4096, False),
+    (((32, 64, True), (40, 64, False)), 1000, False),
+    (((64, 256, True), (64, 256, True), (128, 256, True), (64, 256, True)), 640, True),
+])
+def test_linear_unit_group_bf16_matches_single_units(specs, M, chain):
+    """bf16 storage: the grouped launch runs the same tile code as the single-problem GEMM, so outputs and
+    gradients agree with the one-by-one units to bf16 rounding of accumulated statistics."""
+    import copy
+    from mpa_amd import ops
+    from mpa_amd.modules.pointnet2_utils import Linear, _unit_group
+    torch.manual_seed(3)
+    units = [Linear(k, n, bn=False, act=a).cuda() for k, n, a in specs]
+    ref_units = copy.deepcopy(units)
+    xs = [torch.randn(2, M // 2, k, device="cuda").bfloat16() for k, _, _ in specs]
+    xs_g = [x.clone().requires_grad_(True) for x in xs]
+    xs_r = [x.clone().requires_grad_(True) for x in xs]
+    with ops.feature_dtype(torch.bfloat16):
+        if chain:
+            res = torch.randn(2, M // 2, specs[0][1], device="cuda").bfloat16()
+            outs_g = [_unit_group(units, xs_g, residuals=[res] + [None] * (len(units) - 1), chain=True)]
+            acc = res
+            for u, x in zip(ref_units, xs_r):
+                acc = u.fused(x, acc)
+            outs_r = [acc]
+        else:
+            outs_g = _unit_group(units, xs_g)
+            outs_r = [u(x) for u, x in zip(ref_units, xs_r)]
+        ws = [torch.randn_like(o) for o in outs_r]
+        sum((o.float() * w.float()).sum() for o, w in zip(outs_g, ws)).backward()
+        sum((o.float() * w.float()).sum() for o, w in zip(outs_r, ws)).backward()
+
+    def close(a, b, what, tol):
+        err = ((a.float() - b.float()).norm() / b.float().norm().clamp_min(1e-12)).item()
+        assert err < tol, (what, err)
+
+    for i, (o, r) in enumerate(zip(outs_g, outs_r)):
+        assert o.dtype == torch.bfloat16
+        close(o, r, "out%d" % i, 4e-3)
+    for i, (u, r) in enumerate(zip(units, ref_units)):
+        close(xs_g[i].grad, xs_r[i].grad, "dx%d" % i, 8e-3)
+        close(u.linear.weight.grad, r.linear.weight.grad, "dW%d" % i, 8e-3)
+        close(u.norm2.running_var, r.norm2.running_var, "rvar%d" % i, 1e-4)
