@@ -179,6 +179,31 @@ typedef struct MpaGemmProblem {
     int lda, ldb, ldc, M, N, K, stats_replicas;
 } MpaGemmProblem;
 int mpa_gemm_grouped_f32(const MpaGemmProblem *problems, int count, int transB, void *stream);
+/* Grouped BatchNorm launches for `count` (<= 8) INDEPENDENT Linear units (the units mpa_gemm_grouped_* computed):
+ * forward  y_u = residual_u + lrelu(bn_u(x_u)) exactly as mpa_bn_stats_act_fwd_*, one launch for all units
+ * (sum_mode != 0, all units [M][C]: units[count-1].y = units[0].residual + sum_u lrelu(bn_u(x_u)), added in unit order --
+ * Fuse's sum over its source states, modules/pointnet2_utils.py:617-705); backward reduce / apply as
+ * mpa_bn_act_bwd_reduce_* / _apply_* with mean | invstd taken from `save`.  C % 4 == 0, 16-byte aligned rows
+ * (MPA_EUNSUPPORTED otherwise: use the single-unit entries).  `units` is a HOST array. */
+typedef struct MpaBnUnit {
+    const void *x;                 /* [M][C] rows before normalisation (fp32 or bf16 as the entry says) */
+    const float *stats;            /* forward, training: [stats_replicas][3][C] accumulated tile statistics */
+    float *running_mean, *running_var;
+    int64_t *num_batches_tracked;
+    const float *gamma, *beta;
+    const void *residual;          /* forward, optional */
+    void *y;                       /* forward output */
+    float *save;                   /* [2][C] mean | invstd: written by forward, read by backward */
+    const void *grad_y;            /* backward: upstream gradient, leading dimension ldg */
+    float *partial;                /* backward: [replicas][2][C], zero on entry of the reduce pass */
+    void *grad_x;                  /* backward output */
+    float *dgamma, *dbeta;         /* backward outputs (optional) */
+    int M, C, stats_replicas, ldg, training, replicas;
+    float momentum, eps, slope;
+} MpaBnUnit;
+int mpa_bn_group_fwd_f32(const MpaBnUnit *units, int count, int sum_mode, void *stream);
+int mpa_bn_group_bwd_reduce_f32(const MpaBnUnit *units, int count, void *stream);
+int mpa_bn_group_bwd_apply_f32(const MpaBnUnit *units, int count, void *stream);
 /* Grouped weight gradients: out_p[M,N] = A_p^T B_p for `count` independent problems in one launch
  * (+ one reduce launch), A_p stored [K][M] (lda), B_p stored [K][N] (ldb): dW = dY^T X of every
  * Linear of a backward pass.  Each is a latency-bound stream with a tiny output, so they are
@@ -382,7 +407,9 @@ int mpa_upsample_mean_bwd_bf16(const mpa_bf16 *grad_out, const int64_t *knn_idx,
                                void *stream);
 int mpa_group_col_sum_bf16(const mpa_bf16 *x, int G, int R, int C, int ld, float *out, void *stream);
 int mpa_gemm_grouped_bf16(const MpaGemmProblem *problems, int count, int transB, int b_is_f32, void *stream);
-/*BF16_MORE*/
+int mpa_bn_group_fwd_bf16(const MpaBnUnit *units, int count, int sum_mode, void *stream);
+int mpa_bn_group_bwd_reduce_bf16(const MpaBnUnit *units, int count, void *stream);
+int mpa_bn_group_bwd_apply_bf16(const MpaBnUnit *units, int count, void *stream);
 
 #ifdef __cplusplus
 }

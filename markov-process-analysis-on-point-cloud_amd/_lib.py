@@ -78,6 +78,21 @@ class GemmProblem(ctypes.Structure):
 SIGNATURES["mpa_gemm_grouped_f32"] = [ctypes.POINTER(GemmProblem), _i, _i, _vp]
 
 
+class BnUnit(ctypes.Structure):
+    """struct MpaBnUnit of include/mpa_hip.h"""
+    _fields_ = [("x", _vp), ("stats", _vp), ("running_mean", _vp), ("running_var", _vp), ("num_batches_tracked", _vp),
+                ("gamma", _vp), ("beta", _vp), ("residual", _vp), ("y", _vp), ("save", _vp), ("grad_y", _vp),
+                ("partial", _vp), ("grad_x", _vp), ("dgamma", _vp), ("dbeta", _vp),
+                ("M", _i), ("C", _i), ("stats_replicas", _i), ("ldg", _i), ("training", _i), ("replicas", _i),
+                ("momentum", ctypes.c_float), ("eps", ctypes.c_float), ("slope", ctypes.c_float)]
+
+
+for _sfx in ("f32", "bf16"):
+    SIGNATURES["mpa_bn_group_fwd_" + _sfx] = [ctypes.POINTER(BnUnit), _i, _i, _vp]
+    SIGNATURES["mpa_bn_group_bwd_reduce_" + _sfx] = [ctypes.POINTER(BnUnit), _i, _vp]
+    SIGNATURES["mpa_bn_group_bwd_apply_" + _sfx] = [ctypes.POINTER(BnUnit), _i, _vp]
+
+
 class GemmTnProblemBf16(ctypes.Structure):
     """struct MpaGemmTnProblemBf16 of include/mpa_hip.h"""
     _fields_ = [("A", _vp), ("B", _vp), ("out", _vp), ("a_col_sum", _vp),

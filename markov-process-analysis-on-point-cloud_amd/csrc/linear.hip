@@ -865,14 +865,14 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T *__restrict__ x
 // biased variance M2/M -- no separate finalize launch.  Workgroup 0 also stores (mean, invstd) for the backward
 // pass and updates the running statistics (momentum, unbiased variance) as nn.BatchNorm1d does.  Eval mode
 // (training == 0) normalises with the running statistics.
-template <typename T>
-__global__ __launch_bounds__(256) void bn_stats_act_fwd_kernel(
-    const T *__restrict__ x, const float *__restrict__ stats, int R, int training, float *__restrict__ running_mean,
-    float *__restrict__ running_var, float momentum, float eps, long long *__restrict__ num_batches_tracked,
-    const float *__restrict__ gamma, const float *__restrict__ beta, const T *__restrict__ residual, float slope, int M,
-    int C, T *__restrict__ y, float *__restrict__ save)
+// Prologue shared by the single and grouped forms: scale[C] | shift[C] of one unit into ss; workgroup `bx` == 0 stores
+// (mean, invstd) and updates the running statistics.
+__device__ __forceinline__ void bn_scale_shift(float *ss, const float *__restrict__ stats, int R, int training,
+                                               float *__restrict__ running_mean, float *__restrict__ running_var,
+                                               float momentum, float eps, long long *__restrict__ num_batches_tracked,
+                                               const float *__restrict__ gamma, const float *__restrict__ beta, int M, int C,
+                                               float *__restrict__ save, bool first)
 {
-    extern __shared__ float ss[];          // scale[C], shift[C]
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         float mean, var;
         if (training) {
@@ -891,7 +891,7 @@ __global__ __launch_bounds__(256) void bn_stats_act_fwd_kernel(
         const float sc = gamma[c] * invstd;
         ss[c] = sc;
         ss[C + c] = beta[c] - mean * sc;
-        if (blockIdx.x == 0) {
+        if (first) {
             save[c] = mean;
             save[C + c] = invstd;
             if (training && running_mean != nullptr) {
@@ -901,13 +901,40 @@ __global__ __launch_bounds__(256) void bn_stats_act_fwd_kernel(
             }
         }
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0 && training && num_batches_tracked != nullptr) *num_batches_tracked += 1;
-    __syncthreads();
+    if (first && threadIdx.x == 0 && training && num_batches_tracked != nullptr) *num_batches_tracked += 1;
+}
+
+// Grouped forms (mpa_bn_group_*): up to BN_GROUP_MAX independent units in one launch.
+constexpr int BN_GROUP_MAX = 8;
+struct BnUnit {
+    const void *x;                 // [M][C] pre-normalisation rows (the GEMM's output)
+    const float *stats;            // forward: [R][3][C] accumulated tile statistics
+    float *running_mean, *running_var;
+    long long *nbt;
+    const float *gamma, *beta;
+    const void *residual;          // forward (optional)
+    void *y;                       // forward: output rows
+    float *save;                   // [2][C] mean | invstd
+    const void *gy;                // backward: upstream gradient rows (leading dimension ldg)
+    float *partial;                // backward: [replicas][2][C] channel sums
+    void *gx;                      // backward: gradient of x
+    float *dgamma, *dbeta;
+    int M, C, R, ldg, training, replicas;
+    float momentum, eps, slope;
+};
+struct BnGroupArgs {
+    BnUnit u[BN_GROUP_MAX];
+    int count;
+};
+
+template <typename T>
+__device__ __forceinline__ void bn_apply_rows(const float *ss, const T *__restrict__ x, const T *__restrict__ residual,
+                                              float slope, int M, int C, T *__restrict__ y, int bx, int gx)
+{
     if ((C & 3) == 0) {
         const long long total4 = (long long)M * C / 4;
         const int c4n = C / 4;
-        for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4;
-             i += (long long)gridDim.x * blockDim.x) {
+        for (long long i = bx * (long long)blockDim.x + threadIdx.x; i < total4; i += (long long)gx * blockDim.x) {
             const int c = (int)(i % c4n) * 4;
             const float4 v = mpa_ld4<T>(x + 4 * i);
             const float4 sc = *reinterpret_cast<const float4 *>(ss + c);
@@ -925,13 +952,73 @@ __global__ __launch_bounds__(256) void bn_stats_act_fwd_kernel(
         }
     } else {
         const long long total = (long long)M * C;
-        for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
-             i += (long long)gridDim.x * blockDim.x) {
+        for (long long i = bx * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gx * blockDim.x) {
             const int c = (int)(i % C);
             float t = fmaf(mpa_ld1<T>(x + i), ss[c], ss[C + c]);
             t = t > 0.f ? t : t * slope;
             mpa_st1<T>(y + i, residual != nullptr ? mpa_ld1<T>(residual + i) + t : t);
         }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_stats_act_fwd_kernel(
+    const T *__restrict__ x, const float *__restrict__ stats, int R, int training, float *__restrict__ running_mean,
+    float *__restrict__ running_var, float momentum, float eps, long long *__restrict__ num_batches_tracked,
+    const float *__restrict__ gamma, const float *__restrict__ beta, const T *__restrict__ residual, float slope, int M,
+    int C, T *__restrict__ y, float *__restrict__ save)
+{
+    extern __shared__ float ss[];          // scale[C], shift[C]
+    bn_scale_shift(ss, stats, R, training, running_mean, running_var, momentum, eps, num_batches_tracked, gamma, beta, M, C,
+                   save, blockIdx.x == 0);
+    __syncthreads();
+    bn_apply_rows<T>(ss, x, residual, slope, M, C, y, blockIdx.x, gridDim.x);
+}
+
+// Grouped forward.  sum_mode == 0: blockIdx.y picks the unit, y_u = residual_u + lrelu(bn_u(x_u)).
+// sum_mode != 0 (all units [M][C]): y_last = residual_0 + sum_u lrelu(bn_u(x_u)), added in unit order in fp32 --
+// Fuse's accumulation over its source states in one pass over the rows (intermediate sums never reach memory).
+template <typename T>
+__global__ __launch_bounds__(256) void bn_group_fwd_kernel(BnGroupArgs a, int sum_mode)
+{
+    extern __shared__ float ss[];
+    if (!sum_mode) {
+        const BnUnit &u = a.u[blockIdx.y];
+        bn_scale_shift(ss, u.stats, u.R, u.training, u.running_mean, u.running_var, u.momentum, u.eps, u.nbt, u.gamma,
+                       u.beta, u.M, u.C, u.save, blockIdx.x == 0);
+        __syncthreads();
+        bn_apply_rows<T>(ss, static_cast<const T *>(u.x), static_cast<const T *>(u.residual), u.slope, u.M, u.C,
+                         static_cast<T *>(u.y), blockIdx.x, gridDim.x);
+        return;
+    }
+    const int n = a.count, C = a.u[0].C, M = a.u[0].M;
+    for (int k = 0; k < n; ++k) {
+        const BnUnit &u = a.u[k];
+        bn_scale_shift(ss + (size_t)k * 2 * C, u.stats, u.R, u.training, u.running_mean, u.running_var, u.momentum, u.eps,
+                       u.nbt, u.gamma, u.beta, M, C, u.save, blockIdx.x == 0);
+    }
+    __syncthreads();
+    const T *res = static_cast<const T *>(a.u[0].residual);
+    T *y = static_cast<T *>(a.u[n - 1].y);
+    const long long total4 = (long long)M * C / 4;           // (host: C % 4 == 0)
+    const int c4n = C / 4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c4n) * 4;
+        float4 acc = res != nullptr ? mpa_ld4<T>(res + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < n; ++k) {
+            const float slope = a.u[k].slope;
+            const float4 v = mpa_ld4<T>(static_cast<const T *>(a.u[k].x) + 4 * i);
+            const float4 sc = *reinterpret_cast<const float4 *>(ss + (size_t)k * 2 * C + c);
+            const float4 sh = *reinterpret_cast<const float4 *>(ss + (size_t)k * 2 * C + C + c);
+            float4 o;
+            o.x = fmaf(v.x, sc.x, sh.x); o.y = fmaf(v.y, sc.y, sh.y);
+            o.z = fmaf(v.z, sc.z, sh.z); o.w = fmaf(v.w, sc.w, sh.w);
+            o.x = o.x > 0.f ? o.x : o.x * slope; o.y = o.y > 0.f ? o.y : o.y * slope;
+            o.z = o.z > 0.f ? o.z : o.z * slope; o.w = o.w > 0.f ? o.w : o.w * slope;
+            acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+        }
+        mpa_st4<T>(y + 4 * i, acc);
     }
 }
 
@@ -1053,20 +1140,21 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(
 // rows (4 x 16-B loads) in flight per lane; RY partials combined through LDS, one atomic per
 // (workgroup, channel).
 template <typename T>
-__global__ __launch_bounds__(256) void bn_act_bwd_reduce4_kernel(
+__device__ __forceinline__ void bn_bwd_reduce4_body(
     const T *__restrict__ x, const T *__restrict__ gy, const float *__restrict__ mean,
     const float *__restrict__ invstd, const float *__restrict__ gamma, const float *__restrict__ beta, float slope,
-    int M, int C, int ldg, int lanes_per_row, int rows_per_block, float *__restrict__ partial, int replicas)
+    int M, int C, int ldg, int lanes_per_row, int rows_per_block, float *__restrict__ partial, int replicas, int bx,
+    int by)
 {
     // partial [replicas][2][C] (pre-zeroed): workgroups spread their atomics over the replicas so
     // that at most gridDim.x/replicas of them add into one address; the apply pass sums them.
-    float *__restrict__ sum_g = partial + (size_t)(blockIdx.x % replicas) * 2 * C;
+    float *__restrict__ sum_g = partial + (size_t)(bx % replicas) * 2 * C;
     float *__restrict__ sum_gx = sum_g + C;
     __shared__ float4 red[2][256];
     const int tid = threadIdx.x;
     const int ry = tid / lanes_per_row, cl = tid - ry * lanes_per_row, RY = 256 / lanes_per_row;
-    const int c = (blockIdx.y * lanes_per_row + cl) * 4;
-    const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    const int c = (by * lanes_per_row + cl) * 4;
+    const int r0 = bx * rows_per_block, r1 = min(M, r0 + rows_per_block);
     float4 sg = make_float4(0.f, 0.f, 0.f, 0.f), sx = sg;
     if (c < C && ry < RY) {
         const float4 mu = *reinterpret_cast<const float4 *>(mean + c), is = *reinterpret_cast<const float4 *>(invstd + c);
@@ -1098,7 +1186,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce4_kernel(
     const int cw = lanes_per_row * 4;                    // channels covered by this workgroup
     for (int t = tid; t < 2 * cw; t += 256) {
         const int which = t / cw, ch = t - which * cw;
-        const int cg = blockIdx.y * cw + ch;
+        const int cg = by * cw + ch;
         if (cg < C) {
             float a = 0.f;
             for (int y = 0; y < RY; ++y) a += rf[(size_t)which * 1024 + (y * lanes_per_row + ch / 4) * 4 + (ch & 3)];
@@ -1107,19 +1195,58 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce4_kernel(
     }
 }
 
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_bwd_reduce4_kernel(
+    const T *__restrict__ x, const T *__restrict__ gy, const float *__restrict__ mean,
+    const float *__restrict__ invstd, const float *__restrict__ gamma, const float *__restrict__ beta, float slope,
+    int M, int C, int ldg, int lanes_per_row, int rows_per_block, float *__restrict__ partial, int replicas)
+{
+    bn_bwd_reduce4_body<T>(x, gy, mean, invstd, gamma, beta, slope, M, C, ldg, lanes_per_row, rows_per_block, partial,
+                           replicas, blockIdx.x, blockIdx.y);
+}
+
+// host-side geometry of the float4 reduce: lanes per row, channel blocks, rows per workgroup, row blocks
+struct BnReduceGeom { int lanes, gy, rpb, gx; };
+inline BnReduceGeom bn_reduce_geom(int M, int C)
+{
+    BnReduceGeom g;
+    int lanes = C / 4;                                   // lanes per row: a divisor of 256
+    lanes = lanes >= 256 ? 256 : (lanes > 128 ? 256 : (lanes > 64 ? 128 : (lanes > 32 ? 64 : (lanes > 16 ? 32 : 16))));
+    g.lanes = lanes;
+    g.gy = mpa_ceil_div(C / 4, lanes);
+    const int ry = 256 / lanes;
+    int want = 1024 / g.gy;
+    g.rpb = mpa_ceil_div(M, want < 1 ? 1 : want);
+    if (g.rpb < 2 * ry) g.rpb = 2 * ry;
+    g.gx = mpa_ceil_div(M, g.rpb);
+    return g;
+}
+
+// Grouped backward pass 1: blockIdx.z picks the unit; workgroups outside that unit's own grid leave.
+struct BnGroupGeom { int lanes[BN_GROUP_MAX], gy[BN_GROUP_MAX], rpb[BN_GROUP_MAX], gx[BN_GROUP_MAX]; };
+template <typename T>
+__global__ __launch_bounds__(256) void bn_group_bwd_reduce_kernel(BnGroupArgs a, BnGroupGeom g)
+{
+    const int k = blockIdx.z;
+    if ((int)blockIdx.x >= g.gx[k] || (int)blockIdx.y >= g.gy[k]) return;
+    const BnUnit &u = a.u[k];
+    bn_bwd_reduce4_body<T>(static_cast<const T *>(u.x), static_cast<const T *>(u.gy), u.save, u.save + u.C, u.gamma, u.beta,
+                           u.slope, u.M, u.C, u.ldg, g.lanes[k], g.rpb[k], u.partial, u.replicas, blockIdx.x, blockIdx.y);
+}
+
 // Backward pass 2: grad_x = gamma*invstd*(g - sum_g/M - xhat*sum_gx/M)   (batch statistics)
 //                  grad_x = gamma*invstd*g                                (running statistics)
 template <typename T>
-__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
-    const T *__restrict__ x, const T *__restrict__ gy, const float *__restrict__ mean,
+__device__ __forceinline__ void bn_bwd_apply_body(
+    float *cs, const T *__restrict__ x, const T *__restrict__ gy, const float *__restrict__ mean,
     const float *__restrict__ invstd, const float *__restrict__ gamma, const float *__restrict__ beta,
     const float *__restrict__ partial, int replicas, float slope, int use_batch_stats, int M, int C, int ldg,
-    long long total, T *__restrict__ gx, float *__restrict__ dgamma, float *__restrict__ dbeta)
+    long long total, T *__restrict__ gx, float *__restrict__ dgamma, float *__restrict__ dbeta, int bx, int ngx)
 {
     // per-channel constants in LDS: k1 = gamma*invstd, then grad_x = k1*(g - a - xhat*b) with
     // a = sum_g/M, b = sum_gxhat/M (zero in eval mode); totals of the replicas also go out as
     // dbeta / dgamma (workgroup 0).
-    extern __shared__ float cs[];          // [6][C]: mean, invstd, gamma, beta, a, b
+    // cs [6][C]: mean, invstd, gamma, beta, a, b
     const float invM = 1.0f / (float)M;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         float sg = 0.f, sx = 0.f;
@@ -1141,7 +1268,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
         cs[c] = mean[c]; cs[C + c] = invstd[c]; cs[2 * C + c] = gamma[c]; cs[3 * C + c] = beta[c];
         cs[4 * C + c] = use_batch_stats ? sg * invM : 0.f;
         cs[5 * C + c] = use_batch_stats ? sx * invM : 0.f;
-        if (blockIdx.x == 0) {
+        if (bx == 0) {
             if (dbeta) dbeta[c] = sg;
             if (dgamma) dgamma[c] = sx;
         }
@@ -1152,8 +1279,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
     if (v4) {
         const long long total4 = total / 4;
         const int c4n = C / 4;
-        for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4;
-             i += (long long)gridDim.x * blockDim.x) {
+        for (long long i = bx * (long long)blockDim.x + threadIdx.x; i < total4;
+             i += (long long)ngx * blockDim.x) {
             const long long row = i / c4n;
             const int c = (int)(i - row * c4n) * 4;
             const float4 xv = mpa_ld4<T>(x + 4 * i);
@@ -1172,8 +1299,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
         }
         return;
     }
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
+    for (long long i = bx * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)ngx * blockDim.x) {
         const long long row = i / C;
         const int c = (int)(i - row * C);
         const float is = cs[C + c], ga = cs[2 * C + c];
@@ -1183,6 +1310,29 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
         const float g = t > 0.f ? g0 : g0 * slope;
         mpa_st1<T>(gx + i, ga * is * (g - cs[4 * C + c] - xh * cs[5 * C + c]));
     }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
+    const T *__restrict__ x, const T *__restrict__ gy, const float *__restrict__ mean,
+    const float *__restrict__ invstd, const float *__restrict__ gamma, const float *__restrict__ beta,
+    const float *__restrict__ partial, int replicas, float slope, int use_batch_stats, int M, int C, int ldg,
+    long long total, T *__restrict__ gx, float *__restrict__ dgamma, float *__restrict__ dbeta)
+{
+    extern __shared__ float cs[];
+    bn_bwd_apply_body<T>(cs, x, gy, mean, invstd, gamma, beta, partial, replicas, slope, use_batch_stats, M, C, ldg, total,
+                         gx, dgamma, dbeta, blockIdx.x, gridDim.x);
+}
+
+// Grouped backward pass 2: blockIdx.y picks the unit.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_group_bwd_apply_kernel(BnGroupArgs a)
+{
+    extern __shared__ float cs[];
+    const BnUnit &u = a.u[blockIdx.y];
+    bn_bwd_apply_body<T>(cs, static_cast<const T *>(u.x), static_cast<const T *>(u.gy), u.save, u.save + u.C, u.gamma, u.beta,
+                         u.partial, u.replicas, u.slope, u.training, u.M, u.C, u.ldg, (long long)u.M * u.C,
+                         static_cast<T *>(u.gx), u.dgamma, u.dbeta, blockIdx.x, gridDim.x);
 }
 
 __global__ __launch_bounds__(256) void col_stats_kernel(const float *__restrict__ x, int M, int C, int cpb,
@@ -1489,13 +1639,8 @@ static int bn_act_bwd_reduce_any(const T *x, const T *grad_y, const float *mean,
     const bool al = ((((uintptr_t)x | (uintptr_t)grad_y) & mpa_vec4_align<T>::mask) == 0) &&
                     (((((uintptr_t)mean | (uintptr_t)invstd | (uintptr_t)gamma | (uintptr_t)beta)) & 15) == 0);
     if ((C & 3) == 0 && (ldg & 3) == 0 && al) {
-        int lanes = C / 4;                                   // lanes per row: a divisor of 256
-        lanes = lanes >= 256 ? 256 : (lanes > 128 ? 256 : (lanes > 64 ? 128 : (lanes > 32 ? 64 : (lanes > 16 ? 32 : 16))));
-        const int gy_ = mpa_ceil_div(C / 4, lanes);
-        const int ry = 256 / lanes;
-        int want = 1024 / gy_;
-        int rpb = mpa_ceil_div(M, want < 1 ? 1 : want);
-        if (rpb < 2 * ry) rpb = 2 * ry;
+        const BnReduceGeom g = bn_reduce_geom(M, C);
+        const int lanes = g.lanes, gy_ = g.gy, rpb = g.rpb;
         hipLaunchKernelGGL(bn_act_bwd_reduce4_kernel<T>, dim3(mpa_ceil_div(M, rpb), gy_), dim3(256), 0,
                            (hipStream_t)stream, x, grad_y, mean, invstd, gamma, beta, slope, M, C, ldg, lanes, rpb, partial,
                            replicas);
@@ -1626,6 +1771,123 @@ extern "C" int mpa_bn_stats_act_fwd_bf16(const mpa_bf16 *x, const float *stats, 
                                         running_var, training, momentum, eps, num_batches_tracked, gamma, beta,
                                         reinterpret_cast<const bf16_t *>(residual), slope, reinterpret_cast<bf16_t *>(y),
                                         save_mean_invstd, stream);
+}
+
+// ---- grouped BatchNorm launches (see BnGroupArgs): host structs -> kernel arguments ----------------------------------
+static int bn_group_pack(const MpaBnUnit *units, int count, BnGroupArgs &a, bool bf16)
+{
+    if (!units || count <= 0 || count > BN_GROUP_MAX) return MPA_EINVAL;
+    a.count = count;
+    const uintptr_t mask = bf16 ? 7 : 15;
+    for (int i = 0; i < count; ++i) {
+        const MpaBnUnit &m = units[i];
+        BnUnit &u = a.u[i];
+        if (!m.x || !m.gamma || !m.beta || !m.save || m.M <= 0 || m.C <= 0) return MPA_EINVAL;
+        if ((m.C & 3) != 0 || m.C > 8192) return MPA_EUNSUPPORTED;
+        if ((((uintptr_t)m.x | (uintptr_t)m.y | (uintptr_t)m.residual | (uintptr_t)m.grad_y | (uintptr_t)m.grad_x) & mask) != 0)
+            return MPA_EUNSUPPORTED;
+        u.x = m.x; u.stats = m.stats; u.running_mean = m.running_mean; u.running_var = m.running_var;
+        u.nbt = reinterpret_cast<long long *>(m.num_batches_tracked);
+        u.gamma = m.gamma; u.beta = m.beta; u.residual = m.residual; u.y = m.y; u.save = m.save;
+        u.gy = m.grad_y; u.partial = m.partial; u.gx = m.grad_x; u.dgamma = m.dgamma; u.dbeta = m.dbeta;
+        u.M = m.M; u.C = m.C; u.R = m.stats_replicas; u.ldg = m.ldg; u.training = m.training; u.replicas = m.replicas;
+        u.momentum = m.momentum; u.eps = m.eps; u.slope = m.slope;
+    }
+    return MPA_OK;
+}
+
+template <typename T>
+static int bn_group_fwd_any(const MpaBnUnit *units, int count, int sum_mode, void *stream)
+{
+    MPA_CLEAR_ERROR();
+    BnGroupArgs a;
+    int rc = bn_group_pack(units, count, a, sizeof(T) == 2);
+    if (rc != MPA_OK) return rc;
+    long long most = 0;
+    int cmax = 0;
+    for (int i = 0; i < count; ++i) {
+        const BnUnit &u = a.u[i];
+        if (!u.y && !(sum_mode && i + 1 < count)) return MPA_EINVAL;
+        if (u.training ? (!u.stats || u.R <= 0) : (!u.running_mean || !u.running_var)) return MPA_EINVAL;
+        if (sum_mode && (u.M != a.u[0].M || u.C != a.u[0].C)) return MPA_EINVAL;
+        most = most > (long long)u.M * u.C ? most : (long long)u.M * u.C;
+        cmax = cmax > u.C ? cmax : u.C;
+    }
+    const size_t lds = (size_t)(sum_mode ? count : 1) * 2 * cmax * sizeof(float);
+    if (lds > 64 * 1024) return MPA_EUNSUPPORTED;
+    hipLaunchKernelGGL(bn_group_fwd_kernel<T>, dim3(ew_grid(most / 4 + 1), sum_mode ? 1 : count), dim3(EW_TPB), lds,
+                       (hipStream_t)stream, a, sum_mode);
+    MPA_LAUNCH_CHECK();
+    return MPA_OK;
+}
+
+template <typename T>
+static int bn_group_bwd_reduce_any(const MpaBnUnit *units, int count, void *stream)
+{
+    MPA_CLEAR_ERROR();
+    BnGroupArgs a;
+    int rc = bn_group_pack(units, count, a, sizeof(T) == 2);
+    if (rc != MPA_OK) return rc;
+    BnGroupGeom g;
+    int gx = 0, gy = 0;
+    for (int i = 0; i < count; ++i) {
+        const BnUnit &u = a.u[i];
+        if (!u.gy || !u.partial || u.replicas <= 0 || u.ldg < u.C) return MPA_EINVAL;
+        if ((u.ldg & 3) != 0 || ((uintptr_t)u.gamma | (uintptr_t)u.beta | (uintptr_t)u.save) & 15) return MPA_EUNSUPPORTED;
+        const BnReduceGeom r = bn_reduce_geom(u.M, u.C);
+        g.lanes[i] = r.lanes; g.gy[i] = r.gy; g.rpb[i] = r.rpb; g.gx[i] = r.gx;
+        gx = gx > r.gx ? gx : r.gx;
+        gy = gy > r.gy ? gy : r.gy;
+    }
+    hipLaunchKernelGGL(bn_group_bwd_reduce_kernel<T>, dim3(gx, gy, count), dim3(256), 0, (hipStream_t)stream, a, g);
+    MPA_LAUNCH_CHECK();
+    return MPA_OK;
+}
+
+template <typename T>
+static int bn_group_bwd_apply_any(const MpaBnUnit *units, int count, void *stream)
+{
+    MPA_CLEAR_ERROR();
+    BnGroupArgs a;
+    int rc = bn_group_pack(units, count, a, sizeof(T) == 2);
+    if (rc != MPA_OK) return rc;
+    long long most = 0;
+    int cmax = 0;
+    for (int i = 0; i < count; ++i) {
+        const BnUnit &u = a.u[i];
+        if (!u.gy || !u.partial || !u.gx || u.replicas <= 0 || u.ldg < u.C) return MPA_EINVAL;
+        most = most > (long long)u.M * u.C ? most : (long long)u.M * u.C;
+        cmax = cmax > u.C ? cmax : u.C;
+    }
+    hipLaunchKernelGGL(bn_group_bwd_apply_kernel<T>, dim3(ew_grid(most / 4 + 1), count), dim3(EW_TPB),
+                       6 * cmax * sizeof(float), (hipStream_t)stream, a);
+    MPA_LAUNCH_CHECK();
+    return MPA_OK;
+}
+
+extern "C" int mpa_bn_group_fwd_f32(const MpaBnUnit *units, int count, int sum_mode, void *stream)
+{
+    return bn_group_fwd_any<float>(units, count, sum_mode, stream);
+}
+extern "C" int mpa_bn_group_fwd_bf16(const MpaBnUnit *units, int count, int sum_mode, void *stream)
+{
+    return bn_group_fwd_any<bf16_t>(units, count, sum_mode, stream);
+}
+extern "C" int mpa_bn_group_bwd_reduce_f32(const MpaBnUnit *units, int count, void *stream)
+{
+    return bn_group_bwd_reduce_any<float>(units, count, stream);
+}
+extern "C" int mpa_bn_group_bwd_reduce_bf16(const MpaBnUnit *units, int count, void *stream)
+{
+    return bn_group_bwd_reduce_any<bf16_t>(units, count, stream);
+}
+extern "C" int mpa_bn_group_bwd_apply_f32(const MpaBnUnit *units, int count, void *stream)
+{
+    return bn_group_bwd_apply_any<float>(units, count, stream);
+}
+extern "C" int mpa_bn_group_bwd_apply_bf16(const MpaBnUnit *units, int count, void *stream)
+{
+    return bn_group_bwd_apply_any<bf16_t>(units, count, stream);
 }
 
 extern "C" int mpa_gemm_grouped_f32(const MpaGemmProblem *problems, int count, int transB, void *stream)

@@ -12,7 +12,7 @@ import os
 
 import torch
 
-from ._lib import lib, check, GemmProblem, GemmTnProblem, GemmTnProblemBf16
+from ._lib import lib, check, BnUnit, GemmProblem, GemmTnProblem, GemmTnProblemBf16
 
 _vp = ctypes.c_void_p
 
@@ -1242,18 +1242,23 @@ class _LinearBNActGroup(torch.autograd.Function):
             ys.append(y); stats.append(st); Rs.append(R)
         _gemm_group(probs, 1)
         outs, saved_all, sums_all = [], [], []
-        prev = None
+        arr = (BnUnit * n)()
         for i, ((training, momentum, eps, slope), (x, W, b, gamma, beta, rm, rv, nbt, res)) in enumerate(zip(units_cfg, U)):
             M, N = ys[i].shape
-            out = torch.empty(M, N, dtype=x.dtype, device=dev)
+            last = (not chain) or i == n - 1
+            out = torch.empty(M, N, dtype=x.dtype, device=dev) if last else None
             saved = torch.empty(2, N, dtype=torch.float32, device=dev)
             sums = _zeros_acc(_BN_REPLICAS * 2 * N, dev).view(_BN_REPLICAS, 2, N)
-            r = (prev if (chain and i > 0) else res)
-            _launch("mpa_bn_stats_act_fwd_" + _sfx(ys[i]), _p(ys[i]), _p(stats[i]), Rs[i], M, N, _p(rm), _p(rv), int(training),
-                    float(momentum), float(eps), _p(nbt), _p(gamma), _p(beta), _p(r), float(slope), _p(out), _p(saved),
-                    _stream())
+            u = arr[i]
+            u.x, u.stats, u.running_mean, u.running_var = _p(ys[i]), _p(stats[i]), _p(rm), _p(rv)
+            u.num_batches_tracked, u.gamma, u.beta = _p(nbt), _p(gamma), _p(beta)
+            u.residual = _p(res if (not chain or i == 0) else None)
+            u.y, u.save = _p(out), _p(saved)
+            u.M, u.C, u.stats_replicas, u.training = M, N, Rs[i], int(training)
+            u.momentum, u.eps, u.slope = float(momentum), float(eps), float(slope)
             outs.append(out); saved_all.append(saved); sums_all.append(sums)
-            prev = out
+        # one launch normalises + activates every unit (chain: and sums them onto unit 0's residual in one pass)
+        _launch("mpa_bn_group_fwd_" + _sfx(ys[0]), arr, n, int(chain), _stream())
         keep = []
         for i, (x, W, b, gamma, beta, rm, rv, nbt, res) in enumerate(U):
             keep += [x, W, ys[i], gamma, beta, saved_all[i], sums_all[i]]
@@ -1273,25 +1278,32 @@ class _LinearBNActGroup(torch.autograd.Function):
             raise RuntimeError("_LinearBNActGroup: a second backward through the same node is not supported")
         ctx.ran_backward = True
         gys, probs, gxs = [], [], [None] * n
+        arr = (BnUnit * n)()
+        hold = []
         for i in range(n):
             x, W, y, gamma, beta, saved, sums = S[7 * i:7 * i + 7]
             training, momentum, eps, slope = units_cfg[i]
             M, K = x.shape
             N = W.shape[0]
             gout, ldg = _rows_ld(gouts[0] if chain else gouts[i])
+            if ldg % 4:
+                gout, ldg = gout.contiguous(), N
             dW, db, dgamma, dbeta = ctx.direct[i]
-            _launch("mpa_bn_act_bwd_reduce_" + _sfx(y), _p(y), _p(gout), _p(saved[0]), _p(saved[1]), _p(gamma), _p(beta), slope,
-                    M, N, ldg, _p(sums), _BN_REPLICAS, _stream())
             gy = torch.empty(M, N, dtype=y.dtype, device=dev)
             gg = dgamma if dgamma is not None else torch.empty(N, dtype=torch.float32, device=dev)
             gb_ = dbeta if dbeta is not None else torch.empty(N, dtype=torch.float32, device=dev)
-            _launch("mpa_bn_act_bwd_apply_" + _sfx(y), _p(y), _p(gout), _p(saved[0]), _p(saved[1]), _p(gamma), _p(beta),
-                    _p(sums), _BN_REPLICAS, slope, int(training), M, N, ldg, _p(gy), _p(gg), _p(gb_), _stream())
+            u = arr[i]
+            u.x, u.gamma, u.beta, u.save = _p(y), _p(gamma), _p(beta), _p(saved)
+            u.grad_y, u.partial, u.grad_x, u.dgamma, u.dbeta = _p(gout), _p(sums), _p(gy), _p(gg), _p(gb_)
+            u.M, u.C, u.ldg, u.training, u.replicas, u.slope = M, N, ldg, int(training), _BN_REPLICAS, float(slope)
+            hold.append(gout)
             gys.append((gy, gg, gb_))
             if ctx.needs_input_grad[1 + 9 * i]:
                 gx = torch.empty(M, K, dtype=x.dtype, device=dev)
                 gxs[i] = gx
                 probs.append((gy, N, W, K, None, gx, K, M, K, N, None, 0))
+        _launch("mpa_bn_group_bwd_reduce_" + _sfx(S[2]), arr, n, _stream())
+        _launch("mpa_bn_group_bwd_apply_" + _sfx(S[2]), arr, n, _stream())
         _gemm_group(probs, 0)                                     # dX_i = gy_i W_i: one launch
         grads = []
         for i in range(n):
@@ -1326,7 +1338,8 @@ def linear_bn_act_group(xs, linears, bns, slopes, residuals=None, chain=False):
     or None) with optional residuals -- see _LinearBNActGroup.  chain=True returns residuals[0] + sum_i unit_i(x_i)."""
     n = len(xs)
     residuals = residuals or [None] * n
-    if DETERMINISTIC_BN or n == 1:
+    if (DETERMINISTIC_BN or n == 1 or n > 8 or any(l.weight.shape[0] % 4 for l in linears)
+            or any(x.dtype != xs[0].dtype for x in xs)):
         outs, acc = [], residuals[0]
         for i in range(n):
             o = linear_bn_act(xs[i], linears[i].weight, linears[i].bias, bns[i], slopes[i],

@@ -775,7 +775,7 @@ def test_umbrella_surface_constructor(RS):
         close(m(xyz.transpose(1, 2).contiguous()), g["eval/out"], what="umbrella constructor (eval)")
 
 
-def test_repsurf_2x_baseline_model():
+def test_repsurf_2x_baseline_model(deterministic_bn):
     """models/repsurf/repsurf_ssg_umb_2x.py (umbrella surfaces + ball-query set abstractions incl. the
     global one) against the reference: eval and train-mode log-probabilities, gradient norms."""
     import mpa_amd  # noqa: F401

@@ -1,0 +1,69 @@
+"""Which host lines launch the ATen (non-libmpa) device kernels of one training pass?  Runs a GraphedTrainStep's
+eager pass (same code the graph captures) under torch.profiler with Python stacks and prints, per ATen op and
+calling line, the launch count and device time.   python tools/glue_probe.py [cls|seg] [f32|bf16]"""
+import os
+import sys
+from argparse import Namespace
+from collections import defaultdict
+
+import torch
+from torch.profiler import ProfilerActivity, profile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import mpa_amd  # noqa: E402
+from mpa_amd.runtime import GraphedTrainStep  # noqa: E402
+
+which = sys.argv[1] if len(sys.argv) > 1 else "cls"
+DT = sys.argv[2] if len(sys.argv) > 2 else "f32"
+mpa_amd.ops.set_feature_dtype(torch.bfloat16 if DT == "bf16" else torch.float32)
+dev = torch.device("cuda")
+g = torch.Generator().manual_seed(1)
+if which == "cls":
+    from mpa_amd.models.repsurf.repsurf_ssg_umb import Model, SmoothClsLoss
+    B, N = 64, 1024
+    x = (torch.rand(B, 3, N, generator=g) * 2 - 1).to(dev)
+    y = torch.randint(0, 40, (B,), generator=g).to(dev)
+    model = Model(Namespace(num_point=N, return_dist=True, cuda_ops=True, num_class=40)).to(dev).train()
+    step = GraphedTrainStep(model, SmoothClsLoss(), (x, y), lr=1e-3)
+else:
+    from mpa_amd.models.repsurf.pointnet2_part_seg_msg import get_loss, get_model
+    B, N = 32, 2048
+    x = (torch.rand(B, 3, N, generator=g) * 2 - 1).to(dev)
+    label = torch.zeros(B, 1, 16)
+    label[torch.arange(B), 0, torch.randint(0, 16, (B,), generator=g)] = 1
+    label = label.to(dev)
+    target = torch.randint(0, 50, (B, N), generator=g).to(dev)
+    model = get_model(50).to(dev).train()
+
+    def compute_loss(model, crit, x, label, target):
+        pred, _ = model(x, label)
+        return crit(pred.reshape(-1, 50), target.reshape(-1))
+    step = GraphedTrainStep(model, get_loss(), (x, label, target), lr=1e-3, compute_loss=compute_loss)
+
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+    step._fwd_bwd()
+    torch.cuda.synchronize()
+
+rows = defaultdict(lambda: [0, 0.0])
+for ev in prof.events():
+    if ev.device_time_total <= 0 or not ev.name.startswith("aten::") or ev.cpu_children:
+        # leaf aten ops only (the ones that launch)
+        if not (ev.name.startswith("aten::") and ev.device_time_total > 0 and
+                not any(c.name.startswith("aten::") and c.device_time_total > 0 for c in ev.cpu_children)):
+            continue
+    site = "?"
+    for fr in ev.stack or []:
+        if "markov-process" in fr or "mpa_amd" in fr or "/tools/" in fr:
+            site = fr.replace(ROOT + "/", "")
+            break
+    if site == "?" and ev.stack:
+        site = "(autograd engine)"
+    r = rows[(ev.name, site)]
+    r[0] += 1
+    r[1] += ev.device_time_total
+tot = sum(r[1] for r in rows.values())
+print("ATen device time in one eager pass: %.1f us over %d launching ops" % (tot, sum(r[0] for r in rows.values())))
+for (name, site), (n, t) in sorted(rows.items(), key=lambda kv: -kv[1][1])[:70]:
+    print("%8.1f us %4d  %-28s %s" % (t, n, name, site[-110:]))
