@@ -200,6 +200,7 @@ typedef struct MpaBnUnit {
     float *dgamma, *dbeta;         /* backward outputs (optional) */
     int M, C, stats_replicas, ldg, training, replicas;
     float momentum, eps, slope;
+    int ldy;                       /* forward: leading dimension of y (0 = C): units may write column blocks of one tensor */
 } MpaBnUnit;
 int mpa_bn_group_fwd_f32(const MpaBnUnit *units, int count, int sum_mode, void *stream);
 int mpa_bn_group_bwd_reduce_f32(const MpaBnUnit *units, int count, void *stream);

@@ -84,7 +84,7 @@ class BnUnit(ctypes.Structure):
                 ("gamma", _vp), ("beta", _vp), ("residual", _vp), ("y", _vp), ("save", _vp), ("grad_y", _vp),
                 ("partial", _vp), ("grad_x", _vp), ("dgamma", _vp), ("dbeta", _vp),
                 ("M", _i), ("C", _i), ("stats_replicas", _i), ("ldg", _i), ("training", _i), ("replicas", _i),
-                ("momentum", ctypes.c_float), ("eps", ctypes.c_float), ("slope", ctypes.c_float)]
+                ("momentum", ctypes.c_float), ("eps", ctypes.c_float), ("slope", ctypes.c_float), ("ldy", _i)]
 
 
 for _sfx in ("f32", "bf16"):

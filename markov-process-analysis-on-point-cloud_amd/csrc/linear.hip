@@ -919,7 +919,7 @@ struct BnUnit {
     float *partial;                // backward: [replicas][2][C] channel sums
     void *gx;                      // backward: gradient of x
     float *dgamma, *dbeta;
-    int M, C, R, ldg, training, replicas;
+    int M, C, R, ldg, ldy, training, replicas;
     float momentum, eps, slope;
 };
 struct BnGroupArgs {
@@ -929,13 +929,15 @@ struct BnGroupArgs {
 
 template <typename T>
 __device__ __forceinline__ void bn_apply_rows(const float *ss, const T *__restrict__ x, const T *__restrict__ residual,
-                                              float slope, int M, int C, T *__restrict__ y, int bx, int gx)
+                                              float slope, int M, int C, T *__restrict__ y, int ldy, int bx, int gx)
 {
+    // y rows have leading dimension ldy (a column block of a wider tensor: the units of a group write side by side)
     if ((C & 3) == 0) {
         const long long total4 = (long long)M * C / 4;
         const int c4n = C / 4;
         for (long long i = bx * (long long)blockDim.x + threadIdx.x; i < total4; i += (long long)gx * blockDim.x) {
-            const int c = (int)(i % c4n) * 4;
+            const long long row = i / c4n;
+            const int c = (int)(i - row * c4n) * 4;
             const float4 v = mpa_ld4<T>(x + 4 * i);
             const float4 sc = *reinterpret_cast<const float4 *>(ss + c);
             const float4 sh = *reinterpret_cast<const float4 *>(ss + C + c);
@@ -948,15 +950,16 @@ __device__ __forceinline__ void bn_apply_rows(const float *ss, const T *__restri
                 const float4 r = mpa_ld4<T>(residual + 4 * i);
                 o.x = r.x + o.x; o.y = r.y + o.y; o.z = r.z + o.z; o.w = r.w + o.w;
             }
-            mpa_st4<T>(y + 4 * i, o);
+            mpa_st4<T>(y + row * ldy + c, o);
         }
     } else {
         const long long total = (long long)M * C;
         for (long long i = bx * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gx * blockDim.x) {
-            const int c = (int)(i % C);
+            const long long row = i / C;
+            const int c = (int)(i - row * C);
             float t = fmaf(mpa_ld1<T>(x + i), ss[c], ss[C + c]);
             t = t > 0.f ? t : t * slope;
-            mpa_st1<T>(y + i, residual != nullptr ? mpa_ld1<T>(residual + i) + t : t);
+            mpa_st1<T>(y + row * ldy + c, residual != nullptr ? mpa_ld1<T>(residual + i) + t : t);
         }
     }
 }
@@ -972,7 +975,7 @@ __global__ __launch_bounds__(256) void bn_stats_act_fwd_kernel(
     bn_scale_shift(ss, stats, R, training, running_mean, running_var, momentum, eps, num_batches_tracked, gamma, beta, M, C,
                    save, blockIdx.x == 0);
     __syncthreads();
-    bn_apply_rows<T>(ss, x, residual, slope, M, C, y, blockIdx.x, gridDim.x);
+    bn_apply_rows<T>(ss, x, residual, slope, M, C, y, C, blockIdx.x, gridDim.x);
 }
 
 // Grouped forward.  sum_mode == 0: blockIdx.y picks the unit, y_u = residual_u + lrelu(bn_u(x_u)).
@@ -988,7 +991,7 @@ __global__ __launch_bounds__(256) void bn_group_fwd_kernel(BnGroupArgs a, int su
                        u.beta, u.M, u.C, u.save, blockIdx.x == 0);
         __syncthreads();
         bn_apply_rows<T>(ss, static_cast<const T *>(u.x), static_cast<const T *>(u.residual), u.slope, u.M, u.C,
-                         static_cast<T *>(u.y), blockIdx.x, gridDim.x);
+                         static_cast<T *>(u.y), u.ldy, blockIdx.x, gridDim.x);
         return;
     }
     const int n = a.count, C = a.u[0].C, M = a.u[0].M;
@@ -1479,13 +1482,15 @@ extern "C" int mpa_gemm_tn_grouped_f32(const MpaGemmTnProblem *problems, int cou
     hipStream_t st = (hipStream_t)stream;
     size_t ws_used = 0;
     int done = 0;
+    // more problems than one launch's argument block holds: equal-sized launches (the caller deals them out evenly)
+    const int launches = mpa_ceil_div(count, GROUP_MAX), chunk = mpa_ceil_div(count, launches);
     while (done < count) {
         GroupedArgs ga;
         GroupedReduceArgs ra;
         int n = 0, nr = 0, blocks = 0, rblocks = 0;
         ga.block_start[0] = 0;
         ra.block_start[0] = 0;
-        for (; done < count && n < GROUP_MAX; ++done) {
+        for (; done < count && n < chunk; ++done) {
             const MpaGemmTnProblem &in = problems[done];
             if (!in.A || !in.B || !in.out || in.M <= 0 || in.N <= 0 || in.K <= 0 || in.lda < in.M || in.ldb < in.N)
                 return MPA_EINVAL;
@@ -1791,6 +1796,8 @@ static int bn_group_pack(const MpaBnUnit *units, int count, BnGroupArgs &a, bool
         u.gamma = m.gamma; u.beta = m.beta; u.residual = m.residual; u.y = m.y; u.save = m.save;
         u.gy = m.grad_y; u.partial = m.partial; u.gx = m.grad_x; u.dgamma = m.dgamma; u.dbeta = m.dbeta;
         u.M = m.M; u.C = m.C; u.R = m.stats_replicas; u.ldg = m.ldg; u.training = m.training; u.replicas = m.replicas;
+        u.ldy = m.ldy > 0 ? m.ldy : m.C;
+        if (u.ldy < m.C || (u.ldy & 3) != 0) return MPA_EINVAL;
         u.momentum = m.momentum; u.eps = m.eps; u.slope = m.slope;
     }
     return MPA_OK;

@@ -589,13 +589,15 @@ extern "C" int mpa_gemm_tn_grouped_bf16(const MpaGemmTnProblemBf16 *problems, in
     static const int min_kchunk = getenv("MPA_TN_BF16_KCHUNK") ? atoi(getenv("MPA_TN_BF16_KCHUNK")) : 1024;
     size_t ws_used = 0;
     int done = 0;
+    // more problems than one launch's argument block holds: equal-sized launches (the caller deals them out evenly)
+    const int launches = mpa_ceil_div(count, GROUP_MAX), chunk = mpa_ceil_div(count, launches);
     while (done < count) {
         TnArgs ga;
         GroupedReduceArgs ra;
         int n = 0, nr = 0, blocks = 0, rblocks = 0;
         ga.block_start[0] = 0;
         ra.block_start[0] = 0;
-        for (; done < count && n < GROUP_MAX; ++done) {
+        for (; done < count && n < chunk; ++done) {
             const MpaGemmTnProblemBf16 &in = problems[done];
             if (!in.A || !in.B || !in.out || in.M <= 0 || in.N <= 0 || in.K <= 0 || in.lda < in.M || in.ldb < in.N)
                 return MPA_EINVAL;

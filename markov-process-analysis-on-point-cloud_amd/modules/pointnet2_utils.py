@@ -243,32 +243,40 @@ def stacked_param_groups(t1, t2):
             (t1.q.weight, t2.q.weight), (t1.q.bias, t2.q.bias))
 
 
-def local_trans_pair(t1, t2, features, idx1, idx2, center):
+def local_trans_pair(t1, t2, features, idx1, idx2, center, concat=False):
     """t1(features, idx1), t2(features, idx2) for two feature-branch LocalTrans blocks that share
     their base rows and centres (LocalMerge's two feature streams): the four key/value projections
     are one GEMM over the base rows, the two query projections one GEMM over the centres, and the
     attention backward hands each stacked projection a single gradient."""
     if t1.usetanh or t2.usetanh:
-        return t1(features, idx1, None, center=center), t2(features, idx2, None, center=center)
+        outs = t1(features, idx1, None, center=center), t2(features, idx2, None, center=center)
+        return torch.cat(outs, 2) if concat else outs
     qq = ops.linear_stack(center, (t1.q, t2.q), (True, True))
     kvkv = ops.linear_stack(features, (t1.k, t1.v, t2.k, t2.v), (True, False, True, False))
     c1, c2 = ops.diffattn_pair(qq, kvkv, idx1, idx2)
-    return finish_group((t1, t2), (c1, c2), (center, center))
+    return finish_group((t1, t2), (c1, c2), (center, center), concat=concat)
 
 
-def _unit_group(units, xs, residuals=None, chain=False):
-    """[unit(x)] for independent `Linear` units (BatchNorm form) through ops.linear_bn_act_group: their forward
-    products are one launch and their input-gradient products another."""
+def _unit_group(units, xs, residuals=None, mode="each"):
+    """Independent `Linear` units (BatchNorm form) through ops.linear_bn_act_group: their forward products are one
+    launch and their input-gradient products another.  mode "each": [unit(x)]; "concat": the outputs side by side
+    (torch.cat(..., -1) written in place); "chain": residuals[0] + sum of the units."""
     if any(u.bn_flag for u in units):                          # LayerNorm form (never built by the models)
+        if mode == "chain":
+            acc = residuals[0]
+            for u, x in zip(units, xs):
+                acc = acc + u(x)
+            return acc
         outs = [u.fused(x, None if residuals is None else residuals[i]) for i, (u, x) in enumerate(zip(units, xs))]
-        return outs
+        return torch.cat(outs, -1) if mode == "concat" else outs
     return ops.linear_bn_act_group(list(xs), [u.linear for u in units], [u.norm2 for u in units],
-                                   [0.2 if u.act_flag else None for u in units], residuals=residuals, chain=chain)
+                                   [0.2 if u.act_flag else None for u in units], residuals=residuals, mode=mode)
 
 
-def finish_group(trans, contexts, centers):
-    """[t.finish(context, centre)] for parallel LocalTrans streams: the conv_res units of the streams that have one
-    run as a group, then the ffn units (each with its stream's residual)."""
+def finish_group(trans, contexts, centers, concat=False):
+    """[t.finish(context, centre)] for parallel LocalTrans streams (concat=True: their concatenation along the
+    channels, as LocalMerge feeds it to fc2): the conv_res units of the streams that have one run as a group, then
+    the ffn units (each with its stream's residual)."""
     res = list(centers)
     by_dtype = {}
     for i, t in enumerate(trans):
@@ -278,7 +286,7 @@ def finish_group(trans, contexts, centers):
         outs = _unit_group([trans[i].conv_res for i in members], [centers[i] for i in members])
         for i, o in zip(members, outs):
             res[i] = o
-    return _unit_group([t.ffn for t in trans], list(contexts), residuals=res)
+    return _unit_group([t.ffn for t in trans], list(contexts), residuals=res, mode="concat" if concat else "each")
 
 
 class LocalMerge(nn.Module):
@@ -308,27 +316,27 @@ class LocalMerge(nn.Module):
         else:
             fs = feature if FPS_idx is None else index_points(feature, FPS_idx)
             _, idx_feature = knn_point(self.knn, feature, fs)
-            xyz_f, f1, f2 = self._three_streams(base_xyz, feature, idx, idx_feature, FPS_idx, fs)
-            merge_features = self.fc2(torch.cat((xyz_f, f1, f2), dim=2))
+            merge_features = self.fc2(self._three_streams(base_xyz, feature, idx, idx_feature, FPS_idx, fs))
         if FPS_idx is not None:
             normal = index_points(normal, FPS_idx)
         return merge_features, normal, idx, dist
 
     def _three_streams(self, base_xyz, feature, idx, idx_feature, FPS_idx, fs):
-        """xyz_Trans(base_xyz, idx), feature_Trans1(feature, idx), feature_Trans2(feature, idx_feature): the
-        attention contexts per stream as before, their closing conv_res / ffn units as groups."""
+        """torch.cat((xyz_Trans(base_xyz, idx), feature_Trans1(feature, idx), feature_Trans2(feature, idx_feature)), 2):
+        the attention contexts per stream as before, their closing conv_res / ffn units as groups whose outputs land
+        side by side in one tensor."""
         tx, t1, t2 = self.xyz_Trans, self.feature_Trans1, self.feature_Trans2
         if tx.usetanh or t1.usetanh or t2.usetanh:
             xyz_f = tx(features=base_xyz, idx=idx, pos=base_xyz, FPS_idx=FPS_idx, xyz=True)
             f1, f2 = local_trans_pair(t1, t2, feature, idx, idx_feature, fs)
-            return xyz_f, f1, f2
+            return torch.cat((xyz_f, f1, f2), dim=2)
         cx = index_points(base_xyz, FPS_idx) if FPS_idx is not None else base_xyz
         ctx_x = ops.diffattn_xyz(base_xyz, cx, idx, tx.q.weight, tx.q.bias, tx.k.weight, tx.k.bias, tx.v.weight,
                                  tx.v.bias)
         qq = ops.linear_stack(fs, (t1.q, t2.q), (True, True))
         kvkv = ops.linear_stack(feature, (t1.k, t1.v, t2.k, t2.v), (True, False, True, False))
         c1, c2 = ops.diffattn_pair(qq, kvkv, idx, idx_feature)
-        return finish_group((tx, t1, t2), (ctx_x, c1, c2), (cx, fs, fs))
+        return finish_group((tx, t1, t2), (ctx_x, c1, c2), (cx, fs, fs), concat=True)
 
 
 def _compose(*maps):
@@ -379,12 +387,7 @@ class Fuse(nn.Module):
             ts.append(t)
         # acc = f[dst] + conv_0(t_0) + conv_1(t_1) + ... (same order of additions as the reference's expression):
         # the four products are one grouped launch, every unit's normalise pass adds the running sum as its residual
-        if any(c.bn_flag for c in convs):
-            acc = f[dst]
-            for c, t in zip(convs, ts):
-                acc = acc + c(t)
-        else:
-            acc = _unit_group(convs, ts, residuals=[f[dst]] + [None] * (len(convs) - 1), chain=True)
+        acc = _unit_group(convs, ts, residuals=[f[dst]] + [None] * (len(convs) - 1), mode="chain")
         f[dst] = getattr(self, "conv%d" % dst).fused(acc, f[dst])
         return tuple(f)
 

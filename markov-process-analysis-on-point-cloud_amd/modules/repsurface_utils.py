@@ -179,8 +179,8 @@ class LocalMerge(nn.Module):
         else:
             fs = feature if FPS_idx is None else index_points(feature, FPS_idx)
             _, idx_feature = knn_point(self.knn, feature, fs)
-            f1, f2 = local_trans_pair(self.feature_Trans, self.feature_Trans2, feature, idx, idx_feature, fs)
-            merge_features = self.fc2(torch.cat((f1, f2), dim=2))
+            merge_features = self.fc2(local_trans_pair(self.feature_Trans, self.feature_Trans2, feature, idx,
+                                                       idx_feature, fs, concat=True))
         return merge_features, normal, idx, dist
 
 

@@ -716,8 +716,31 @@ def _gemm_bf16(A, lda, tA, Bm, ldb, tB, bias, C, ldc, M, N, K, accumulate, tile_
             algo_flops=2 * M * N * K, tag=(M, N, K, tA, tB, tile_stats is not None))
 
 
+_DW_GROUP_MAX = 40          # GROUP_MAX of csrc/splitk_reduce.h: problems per grouped weight-gradient launch
+
+
+def _deal_weight_grads(queue):
+    """Order of the queued dW problems when they need more than one launch (the entry points cut `count` problems
+    into ceil(count/40) equal runs): the single-tile problems of the fine states (long HBM-bound streams) and the
+    wide ones of the coarse states (MFMA-bound tiles) are dealt out evenly, streams first inside every launch, so
+    each launch overlaps the two kinds instead of one launch holding all the streams."""
+    n = len(queue)
+    launches = -(-n // _DW_GROUP_MAX)
+    if launches <= 1:
+        return queue
+
+    def key(q):
+        M, N, K = q[5], q[6], q[7]
+        tiles = ((M + 63) // 64) * ((N + 63) // 64)
+        return (0 if tiles <= 4 else 1, -M * N * K)
+
+    order = sorted(queue, key=key)
+    return [q for r in range(launches) for q in order[r::launches]]     # run r = every launches-th problem
+
+
 def _weight_grads_bf16(queue):
     """queue entries: (gy, lda, x, ldb, out, M, N, K, a_col_sum) with bf16 gy / x and fp32 out."""
+    queue = _deal_weight_grads(queue)
     n = len(queue)
     arr = (GemmTnProblemBf16 * n)()
     ws_bytes = 0
@@ -820,6 +843,7 @@ def flush_weight_grads():
     if q16:
         _weight_grads_bf16(q16)
     if q32:
+        q32 = _deal_weight_grads(q32)
         n = len(q32)
         arr = (GemmTnProblem * n)()
         ws_bytes = 0
@@ -1218,15 +1242,20 @@ class _LinearBNAct(torch.autograd.Function):
 
 class _LinearBNActGroup(torch.autograd.Function):
     """n INDEPENDENT Linear -> BatchNorm1d -> LeakyReLU (+ residual) units in one autograd node: their forward
-    products are one grouped launch, their dX products another (the units of LocalMerge's parallel attention
-    streams and of Fuse's four source states are ~1 GFLOP each: alone they leave the chip half empty).
-    chain=True: unit i's residual is unit i-1's output (unit 0's is the given one) and only the last output is
-    returned -- acc + sum_i unit_i(x_i), Fuse's accumulation, without the separate additions.
+    products are one grouped launch, their dX products another, and so are the three BatchNorm passes (the units of
+    LocalMerge's parallel attention streams and of Fuse's four source states are ~1 GFLOP each: alone they leave
+    the chip half empty).  mode:
+      "each"    n outputs;
+      "concat"  one output [M, sum N_i], the units' outputs side by side (torch.cat((f1, f2), 2) without the copy:
+                every unit writes its column block, backward reads its block of the gradient in place);
+      "chain"   one output, residual_0 + sum_i unit_i(x_i) added in unit order (Fuse's accumulation over its source
+                states: one pass over the rows, no intermediate sums in memory).
     ts: 9 tensors per unit -- x [M,K], W, b, gamma, beta, running_mean, running_var, num_batches_tracked, residual."""
 
     @staticmethod
     def forward(ctx, cfg, *ts):
-        units_cfg, chain = cfg
+        units_cfg, mode = cfg
+        chain, concat = mode == "chain", mode == "concat"
         n = len(units_cfg)
         U = [ts[9 * i:9 * i + 9] for i in range(n)]
         dev = U[0][0].device
@@ -1243,10 +1272,18 @@ class _LinearBNActGroup(torch.autograd.Function):
         _gemm_group(probs, 1)
         outs, saved_all, sums_all = [], [], []
         arr = (BnUnit * n)()
+        wide = None
+        if concat:
+            Nt = sum(y.shape[1] for y in ys)
+            wide = torch.empty(ys[0].shape[0], Nt, dtype=ys[0].dtype, device=dev)
+        off = 0
         for i, ((training, momentum, eps, slope), (x, W, b, gamma, beta, rm, rv, nbt, res)) in enumerate(zip(units_cfg, U)):
             M, N = ys[i].shape
-            last = (not chain) or i == n - 1
-            out = torch.empty(M, N, dtype=x.dtype, device=dev) if last else None
+            if concat:
+                out = wide[:, off:off + N]
+                off += N
+            else:
+                out = torch.empty(M, N, dtype=x.dtype, device=dev) if ((not chain) or i == n - 1) else None
             saved = torch.empty(2, N, dtype=torch.float32, device=dev)
             sums = _zeros_acc(_BN_REPLICAS * 2 * N, dev).view(_BN_REPLICAS, 2, N)
             u = arr[i]
@@ -1254,6 +1291,7 @@ class _LinearBNActGroup(torch.autograd.Function):
             u.num_batches_tracked, u.gamma, u.beta = _p(nbt), _p(gamma), _p(beta)
             u.residual = _p(res if (not chain or i == 0) else None)
             u.y, u.save = _p(out), _p(saved)
+            u.ldy = wide.shape[1] if concat else N
             u.M, u.C, u.stats_replicas, u.training = M, N, Rs[i], int(training)
             u.momentum, u.eps, u.slope = float(momentum), float(eps), float(slope)
             outs.append(out); saved_all.append(saved); sums_all.append(sums)
@@ -1263,31 +1301,44 @@ class _LinearBNActGroup(torch.autograd.Function):
         for i, (x, W, b, gamma, beta, rm, rv, nbt, res) in enumerate(U):
             keep += [x, W, ys[i], gamma, beta, saved_all[i], sums_all[i]]
         ctx.save_for_backward(*keep)
-        ctx.cfg = (units_cfg, chain, [u[2] is not None for u in U], [u[8] is not None for u in U])
+        ctx.cfg = (units_cfg, mode, [u[2] is not None for u in U], [u[8] is not None for u in U])
         ctx.direct = [(_direct(u[1]), _direct(u[2]), _direct(u[3]), _direct(u[4])) for u in U]
         ctx.ran_backward = False
+        if concat:
+            return wide
         return outs[-1] if chain else tuple(outs)
 
     @staticmethod
     def backward(ctx, *gouts):
-        units_cfg, chain, has_bias, has_res = ctx.cfg
+        units_cfg, mode, has_bias, has_res = ctx.cfg
+        chain, concat = mode == "chain", mode == "concat"
         n = len(units_cfg)
         S = ctx.saved_tensors
         dev = S[0].device
         if ctx.ran_backward:
             raise RuntimeError("_LinearBNActGroup: a second backward through the same node is not supported")
         ctx.ran_backward = True
-        gys, probs, gxs = [], [], [None] * n
+        gys, probs, gxs, g_in = [], [], [None] * n, []
         arr = (BnUnit * n)()
-        hold = []
+        wide = ldw = None
+        if concat:
+            wide, ldw = _rows_ld(gouts[0])
+            if ldw % 4:
+                wide = wide.contiguous()
+                ldw = wide.shape[1]
+        off = 0
         for i in range(n):
             x, W, y, gamma, beta, saved, sums = S[7 * i:7 * i + 7]
             training, momentum, eps, slope = units_cfg[i]
             M, K = x.shape
             N = W.shape[0]
-            gout, ldg = _rows_ld(gouts[0] if chain else gouts[i])
-            if ldg % 4:
-                gout, ldg = gout.contiguous(), N
+            if concat:
+                gout, ldg = wide[:, off:off + N], ldw
+                off += N
+            else:
+                gout, ldg = _rows_ld(gouts[0] if chain else gouts[i])
+                if ldg % 4:
+                    gout, ldg = gout.contiguous(), N
             dW, db, dgamma, dbeta = ctx.direct[i]
             gy = torch.empty(M, N, dtype=y.dtype, device=dev)
             gg = dgamma if dgamma is not None else torch.empty(N, dtype=torch.float32, device=dev)
@@ -1296,7 +1347,7 @@ class _LinearBNActGroup(torch.autograd.Function):
             u.x, u.gamma, u.beta, u.save = _p(y), _p(gamma), _p(beta), _p(saved)
             u.grad_y, u.partial, u.grad_x, u.dgamma, u.dbeta = _p(gout), _p(sums), _p(gy), _p(gg), _p(gb_)
             u.M, u.C, u.ldg, u.training, u.replicas, u.slope = M, N, ldg, int(training), _BN_REPLICAS, float(slope)
-            hold.append(gout)
+            g_in.append(gout)
             gys.append((gy, gg, gb_))
             if ctx.needs_input_grad[1 + 9 * i]:
                 gx = torch.empty(M, K, dtype=x.dtype, device=dev)
@@ -1326,18 +1377,19 @@ class _LinearBNActGroup(torch.autograd.Function):
                     _col_sum_into(gy, db)
                 else:
                     gb = _col_sum(gy)
-            gout = gouts[0] if chain else gouts[i]
-            gres = gout if (has_res[i] and (not chain or i == 0)) else None
+            gres = g_in[i] if (has_res[i] and (not chain or i == 0)) else None
             grads += [gxs[i], gW, gb, None if dgamma is not None else gg, None if dbeta is not None else gb_, None, None,
                       None, gres]
         return (None,) + tuple(grads)
 
 
-def linear_bn_act_group(xs, linears, bns, slopes, residuals=None, chain=False):
-    """[unit_i(x_i)] for n independent Linear units (nn.Linear `linears[i]`, nn.BatchNorm1d `bns[i]`, LeakyReLU slope
-    or None) with optional residuals -- see _LinearBNActGroup.  chain=True returns residuals[0] + sum_i unit_i(x_i)."""
+def linear_bn_act_group(xs, linears, bns, slopes, residuals=None, mode="each"):
+    """The n independent Linear units (nn.Linear `linears[i]`, nn.BatchNorm1d `bns[i]`, LeakyReLU slope or None) with
+    optional residuals, see _LinearBNActGroup: mode "each" -> [unit_i(x_i)], "concat" -> torch.cat of them along the
+    channels, "chain" -> residuals[0] + sum_i unit_i(x_i)."""
     n = len(xs)
     residuals = residuals or [None] * n
+    chain, concat = mode == "chain", mode == "concat"
     if (DETERMINISTIC_BN or n == 1 or n > 8 or any(l.weight.shape[0] % 4 for l in linears)
             or any(x.dtype != xs[0].dtype for x in xs)):
         outs, acc = [], residuals[0]
@@ -1346,7 +1398,7 @@ def linear_bn_act_group(xs, linears, bns, slopes, residuals=None, chain=False):
                               residual=(acc if chain else residuals[i]))
             outs.append(o)
             acc = o
-        return outs[-1] if chain else outs
+        return outs[-1] if chain else (torch.cat(outs, -1) if concat else outs)
     _dev(*xs)
     lead = [x.shape[:-1] for x in xs]
     cfg, ts = [], []
@@ -1363,9 +1415,11 @@ def linear_bn_act_group(xs, linears, bns, slopes, residuals=None, chain=False):
                     1.0 if slopes[i] is None else slopes[i]))
         ts += [x2, _f32(W), linears[i].bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                bn.num_batches_tracked if training else None, res2]
-    out = _LinearBNActGroup.apply((tuple(cfg), bool(chain)), *ts)
+    out = _LinearBNActGroup.apply((tuple(cfg), mode), *ts)
     if chain:
         return out.view(*lead[-1], linears[-1].weight.shape[0])
+    if concat:
+        return out.view(*lead[0], out.shape[-1])
     return [o.view(*lead[i], linears[i].weight.shape[0]) for i, o in enumerate(out)]
 
 

@@ -452,7 +452,7 @@ def test_linear_unit_group_bf16_matches_single_units(specs, M, chain):
     with ops.feature_dtype(torch.bfloat16):
         if chain:
             res = torch.randn(2, M // 2, specs[0][1], device="cuda").bfloat16()
-            outs_g = [_unit_group(units, xs_g, residuals=[res] + [None] * (len(units) - 1), chain=True)]
+            outs_g = [_unit_group(units, xs_g, residuals=[res] + [None] * (len(units) - 1), mode="chain")]
             acc = res
             for u, x in zip(ref_units, xs_r):
                 acc = u.fused(x, acc)

@@ -868,7 +868,7 @@ def test_linear_unit_group_matches_single_units(specs, M, chain):
     if chain:
         res_g = torch.randn(2, M // 2, n_out, device="cuda", requires_grad=True)
         res_r = res_g.detach().clone().requires_grad_(True)
-        out_g = _unit_group(units, xs_g, residuals=[res_g] + [None] * (len(units) - 1), chain=True)
+        out_g = _unit_group(units, xs_g, residuals=[res_g] + [None] * (len(units) - 1), mode="chain")
         acc = res_r
         for u, x in zip(ref_units, xs_r):
             acc = acc + u(x)
@@ -915,3 +915,36 @@ def test_linear_unit_group_eval_mode():
         outs = _unit_group(units, xs)
         for u, x, o in zip(units, xs, outs):
             assert torch.allclose(o, u(x), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 8e-3)])
+def test_linear_unit_group_concat_mode(dtype, tol):
+    """mode="concat": the units write column blocks of ONE tensor (LocalMerge's torch.cat((f1, f2), 2) without the
+    copy) and read their blocks of the upstream gradient in place."""
+    import copy
+    from mpa_amd import ops
+    from mpa_amd.modules.pointnet2_utils import _unit_group
+    specs = ((64, 128, True), (64, 128, True), (32, 64, True))
+    units, xs = _group_units(specs, 1024, dtype)
+    ref_units = copy.deepcopy(units)
+    xs_g = [x.clone().requires_grad_(True) for x in xs]
+    xs_r = [x.clone().requires_grad_(True) for x in xs]
+    res = [torch.randn(2, 512, n, device="cuda").to(dtype) for _, n, _ in specs]
+    with ops.feature_dtype(dtype):
+        got = _unit_group(units, xs_g, residuals=res, mode="concat")
+        want = torch.cat([u.fused(x, r) for u, x, r in zip(ref_units, xs_r, res)], 2)
+        assert got.shape == want.shape == (2, 512, 320) and got.dtype == dtype
+        w = torch.randn_like(want)
+        (got.float() * w.float()).sum().backward()
+        (want.float() * w.float()).sum().backward()
+
+    def close(a, b, what):
+        err = ((a.float() - b.float()).norm() / b.float().norm().clamp_min(1e-12)).item()
+        assert err < tol, (what, err)
+
+    close(got, want, "out")
+    for i, (u, r) in enumerate(zip(units, ref_units)):
+        close(xs_g[i].grad, xs_r[i].grad, "dx%d" % i)
+        close(u.linear.weight.grad, r.linear.weight.grad, "dW%d" % i)
+        close(u.norm2.weight.grad, r.norm2.weight.grad, "dgamma%d" % i)

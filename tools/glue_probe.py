@@ -4,7 +4,6 @@ calling line, the launch count and device time.   python tools/glue_probe.py [cl
 import os
 import sys
 from argparse import Namespace
-from collections import defaultdict
 
 import torch
 from torch.profiler import ProfilerActivity, profile
@@ -46,24 +45,5 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stac
     step._fwd_bwd()
     torch.cuda.synchronize()
 
-rows = defaultdict(lambda: [0, 0.0])
-for ev in prof.events():
-    if ev.device_time_total <= 0 or not ev.name.startswith("aten::") or ev.cpu_children:
-        # leaf aten ops only (the ones that launch)
-        if not (ev.name.startswith("aten::") and ev.device_time_total > 0 and
-                not any(c.name.startswith("aten::") and c.device_time_total > 0 for c in ev.cpu_children)):
-            continue
-    site = "?"
-    for fr in ev.stack or []:
-        if "markov-process" in fr or "mpa_amd" in fr or "/tools/" in fr:
-            site = fr.replace(ROOT + "/", "")
-            break
-    if site == "?" and ev.stack:
-        site = "(autograd engine)"
-    r = rows[(ev.name, site)]
-    r[0] += 1
-    r[1] += ev.device_time_total
-tot = sum(r[1] for r in rows.values())
-print("ATen device time in one eager pass: %.1f us over %d launching ops" % (tot, sum(r[0] for r in rows.values())))
-for (name, site), (n, t) in sorted(rows.items(), key=lambda kv: -kv[1][1])[:70]:
-    print("%8.1f us %4d  %-28s %s" % (t, n, name, site[-110:]))
+print(prof.key_averages(group_by_input_shape=True).table(sort_by="self_device_time_total", row_limit=90,
+                                                          max_name_column_width=60, max_shapes_column_width=70))
