@@ -716,31 +716,8 @@ def _gemm_bf16(A, lda, tA, Bm, ldb, tB, bias, C, ldc, M, N, K, accumulate, tile_
             algo_flops=2 * M * N * K, tag=(M, N, K, tA, tB, tile_stats is not None))
 
 
-_DW_GROUP_MAX = 40          # GROUP_MAX of csrc/splitk_reduce.h: problems per grouped weight-gradient launch
-
-
-def _deal_weight_grads(queue):
-    """Order of the queued dW problems when they need more than one launch (the entry points cut `count` problems
-    into ceil(count/40) equal runs): the single-tile problems of the fine states (long HBM-bound streams) and the
-    wide ones of the coarse states (MFMA-bound tiles) are dealt out evenly, streams first inside every launch, so
-    each launch overlaps the two kinds instead of one launch holding all the streams."""
-    n = len(queue)
-    launches = -(-n // _DW_GROUP_MAX)
-    if launches <= 1:
-        return queue
-
-    def key(q):
-        M, N, K = q[5], q[6], q[7]
-        tiles = ((M + 63) // 64) * ((N + 63) // 64)
-        return (0 if tiles <= 4 else 1, -M * N * K)
-
-    order = sorted(queue, key=key)
-    return [q for r in range(launches) for q in order[r::launches]]     # run r = every launches-th problem
-
-
 def _weight_grads_bf16(queue):
     """queue entries: (gy, lda, x, ldb, out, M, N, K, a_col_sum) with bf16 gy / x and fp32 out."""
-    queue = _deal_weight_grads(queue)
     n = len(queue)
     arr = (GemmTnProblemBf16 * n)()
     ws_bytes = 0
@@ -843,7 +820,6 @@ def flush_weight_grads():
     if q16:
         _weight_grads_bf16(q16)
     if q32:
-        q32 = _deal_weight_grads(q32)
         n = len(q32)
         arr = (GemmTnProblem * n)()
         ws_bytes = 0
