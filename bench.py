@@ -50,8 +50,9 @@ CONFIGS = {
 # product of the path is below the machine balance (32..200 FLOP/B against ~310), so all are priced on HBM.
 TIMED = {
     "f32": {"mpa_gemm_f32/tiled": "mfma", "mpa_gemm_f32/shortk": "hbm", "mpa_gemm_tn_grouped_f32": "mfma",
-            "mpa_knn_f32": "mfma", "mpa_diffattn_fwd_f32": "hbm", "mpa_diffattn_bwd_f32": "hbm"},
-    "bf16": {"mpa_gemm_bf16": "hbm", "mpa_gemm_tn_grouped_bf16": "hbm", "mpa_knn_f32": "mfma",
+            "mpa_gemm_grouped_f32": "mfma", "mpa_knn_f32": "mfma", "mpa_diffattn_fwd_f32": "hbm", "mpa_diffattn_bwd_f32": "hbm"},
+    "bf16": {"mpa_gemm_bf16": "hbm", "mpa_gemm_tn_grouped_bf16": "hbm", "mpa_gemm_grouped_bf16": "hbm",
+             "mpa_knn_f32": "mfma",
              "mpa_diffattn_fwd_bf16": "hbm", "mpa_diffattn_bwd_bf16": "hbm"},
 }
 NUM_CLASS, NUM_PART, NUM_OBJ = 40, 50, 16
@@ -375,6 +376,15 @@ def main():
             "roofline": roof,
             "roofline_other_kernels": kernels[1:],
         }
+        kn = kt.get("mpa_knn_f32")
+        if kn and kn["launches"]:
+            # SURVEY 8(d)'s unit for the grouping kernel: query x base-point distance evaluations (each over the
+            # launch's C channels: xyz searches have C = 3, feature-space searches C = 64..256)
+            line["knn"] = {"distance_evals_per_s": kn["algo_units"] / (kn["ms"] / 1e3),
+                           "distance_evals_per_step": kn["algo_units"] / min(a.steps, 10) if not a.eager else
+                           kn["algo_units"] / a.steps,
+                           "launches_per_step": kn["launches"] / (min(a.steps, 10) if not a.eager else a.steps),
+                           "ms_per_step": kn["ms"] / (min(a.steps, 10) if not a.eager else a.steps)}
         if world == 1 and not a.eager and not a.no_forward_only:
             line["forward_only"] = forward_only(run_forward, graphed.feeder, graphed.arena, batch)
         if world == 1 and not a.no_cpu_baseline:

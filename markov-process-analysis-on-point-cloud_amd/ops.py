@@ -41,16 +41,18 @@ def disable_kernel_timing():
 
 
 def kernel_timing_results():
-    """-> {name: {"launches", "ms", "algo_bytes", "algo_flops"}} totals (synchronises)."""
+    """-> {name: {"launches", "ms", "algo_bytes", "algo_flops", "algo_units"}} totals (synchronises).  algo_units: the
+    kernel's own unit of work where it has one (kNN: query-base distance evaluations)."""
     torch.cuda.synchronize()
     out = {}
     for name, recs in (_TIMERS or {}).items():
-        out[name] = {"launches": len(recs), "ms": sum(a.elapsed_time(b) for a, b, _, _ in recs),
-                     "algo_bytes": sum(n for _, _, n, _ in recs), "algo_flops": sum(f for _, _, _, f in recs)}
+        out[name] = {"launches": len(recs), "ms": sum(r[0].elapsed_time(r[1]) for r in recs),
+                     "algo_bytes": sum(r[2] for r in recs), "algo_flops": sum(r[3] for r in recs),
+                     "algo_units": sum(r[4] for r in recs)}
     return out
 
 
-def _launch(name, *args, algo_bytes=0, algo_flops=0, tag=None, variant=None):
+def _launch(name, *args, algo_bytes=0, algo_flops=0, algo_units=0, tag=None, variant=None):
     # variant: which device kernel the entry point will pick ("mpa_gemm_f32/shortk"), so that the
     # roofline leg can price HBM-bound and MFMA-bound launches of one entry point separately
     fn = getattr(lib, name)
@@ -66,7 +68,7 @@ def _launch(name, *args, algo_bytes=0, algo_flops=0, tag=None, variant=None):
     e0.record()
     check(fn(*args), name)
     e1.record()
-    recs.append((e0, e1, algo_bytes, algo_flops))
+    recs.append((e0, e1, algo_bytes, algo_flops, algo_units))
     if _TAGS is not None:
         _TAGS.append((name, tag, e0, e1))
 
@@ -263,7 +265,7 @@ def knn_point(nsample, xyz, new_xyz):
     dist = torch.empty(B, S, nsample, dtype=torch.float32, device=base.device)
     idx = torch.empty(B, S, nsample, dtype=torch.int64, device=base.device)
     _launch("mpa_knn_f32", _p(base), _p(query), B, N, S, C, nsample, _p(dist), _p(idx), _stream(),
-            algo_bytes=B * (4 * C * (S + N) + 12 * S * nsample), algo_flops=2 * B * S * N * C)
+            algo_bytes=B * (4 * C * (S + N) + 12 * S * nsample), algo_flops=2 * B * S * N * C, algo_units=B * S * N)
     return dist, idx
 
 

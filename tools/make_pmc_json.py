@@ -25,6 +25,8 @@ ENTRY = {          # C-ABI entry point -> (main kernel prefix, helper kernel pre
     "mpa_gemm_f32/tiled": ("gemm_kernel<", ["splitk_reduce_kernel"]),
     "mpa_gemm_f32/shortk": ("gemm_shortk_kernel<", []),
     "mpa_gemm_tn_grouped_f32": ("gemm_tn_grouped_kernel", ["splitk_reduce_grouped_kernel"]),
+    "mpa_gemm_grouped_f32": ("gemm_nt_grouped_kernel<", []),
+    "mpa_gemm_grouped_bf16": ("gemm_bf16_grouped_kernel<", []),
     "mpa_knn_f32": ("knn_mfma_kernel<", []),
     "mpa_diffattn_fwd_f32": ("diffattn_fwd", []),
     "mpa_diffattn_bwd_f32": ("diffattn_bwd_p1", ["diffattn_bwd_p2", "csr_build_kernel"]),
