@@ -71,6 +71,13 @@ int mpa_square_distance_f32(const float *src, const float *dst, int B, int S, in
  * C in {1..8, 16, 32, 64, 128, 256, 512}; K <= 32; K <= N. */
 int mpa_knn_f32(const float *base, const float *query, int B, int N, int S, int C, int K,
                 float *out_dist, int64_t *out_idx, void *stream);
+/* The same search with the base rows' squared norms given: norms [B][ceil32(N)] from mpa_row_norms_f32 (the reference's
+ * `torch.sum(dst ** 2, -1)`, modules/pointnet2_utils.py:207, rounded as there; +inf in the padding).  One small launch
+ * computes them once per search instead of once per (32-query workgroup, pass, tile) inside it.  Results are identical
+ * to mpa_knn_f32's bit for bit.  C in {32, 64, 128, 256} use the norms; other widths ignore them. */
+int mpa_row_norms_f32(const float *x, int B, int N, int C, float *norms, void *stream);
+int mpa_knn_norms_f32(const float *base, const float *base_norms, const float *query, int B, int N, int S, int C,
+                      int K, float *out_dist, int64_t *out_idx, void *stream);
 
 /* FPS of one point-set state and the xyz-space (C = 3) kNN of the previous state in one launch:
  * mpa_fps_f32(fps_xyz [B,fps_N,3] -> fps_idx [B,fps_S], fps_out_xyz) and

@@ -13,6 +13,7 @@
 #include "mpa_common.h"
 #include "fps_body.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -386,42 +387,89 @@ __device__ __forceinline__ bool lex_less(float d1, int n1, float d2, int n2)
 constexpr int KNN_CAP = 32;      // candidates kept per query in pass B
 constexpr int KNN_G = 32;        // groups per query in pass A
 
-template <int CT, int WAVES, int KMAX>
+// QG: 32-query groups per workgroup.  With QG = 2 every staged base tile (LDS rows, norms) feeds two independent MFMA
+// chains: half the staging / norm / LDS-read work per product, and a tile's MFMA phase (2 x C/2 instructions) is long
+// enough to cover the next tile's global load -- with one group the load of the following tile (an L2 hit, 0.6-0.9 us)
+// is as long as the 0.85 us of MFMAs it hides behind at C = 64, and the matrix cores idle about half the time.
+// RES (C = 3 searches, N <= KNN_RES_MAX): the whole base cloud and its norms are staged ONCE per workgroup
+// ([N][4] floats + [N] norms, <= 20 bytes per point) and both passes run out of LDS.  A C = 3 tile is two MFMAs: with
+// per-tile staging every visit costs a global-load latency (~1 us for 128 cycles of MFMA); resident, a visit is the
+// two MFMAs plus the selection arithmetic.
+constexpr int KNN_RES_MAX = 4096;
+
+template <int CT, int WAVES, int KMAX, int QG = 1, bool RES = false, bool GN = false>
 __device__ __forceinline__ void knn_mfma_body(const float *__restrict__ base, const float *__restrict__ query, int N,
                                               int S, int K, float *__restrict__ out_dist,
-                                              int64_t *__restrict__ out_idx, const int bx, const int by, float *lds)
+                                              int64_t *__restrict__ out_idx, const int bx, const int by, float *lds,
+                                              const float *__restrict__ bnorm = nullptr)
 {
+    // GN: bnorm holds the base rows' squared norms [B][ceil32(N)] from mpa_row_norms_f32 (+inf past N).  Without it
+    // every workgroup recomputes the norms of every tile in both passes: ~140 dependent VALU instructions on 32 of a
+    // wave's lanes per tile, a quarter to a half of the tile's MFMA time at C = 64.  (A template parameter, not a
+    // run-time test: with both forms alive the two-group kernel needs 280 registers and loses its second wave per SIMD.)
+    static_assert(!(GN && RES), "resident clouds compute their norms once per workgroup");
     constexpr int CP = (CT + 3) & ~3;            // channels padded to a float4 multiple (C=3 -> 4)
     constexpr int PITCH = CP + 4;                // LDS row pitch: (PITCH/4) odd -> conflict-free b128 rows
     constexpr int NV = 32 * CP / 4 / 64;         // float4 staged per lane per tile (CP >= 8)
     constexpr int NT_ = WAVES * 64;
+    constexpr int NQ = 32 * QG;                  // queries per workgroup
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
+    static_assert(!RES || CT == 3, "resident clouds: coordinate searches only");
     float *slab = lds + wave * (32 * PITCH + 32);          // [32][PITCH] tile + [32] norms
     float *snorm = slab + 32 * PITCH;
-    int *gmin = reinterpret_cast<int *>(lds + WAVES * (32 * PITCH + 32));   // [KNN_G][32] keys
-    float *tau = reinterpret_cast<float *>(gmin + KNN_G * 32);              // [32]
-    int *cnt = reinterpret_cast<int *>(tau + 32);                           // [32] (+ overflow flag at [32])
-    float *cand_d = reinterpret_cast<float *>(cnt + 64);                    // [32][KNN_CAP]
-    int *cand_i = reinterpret_cast<int *>(cand_d + 32 * KNN_CAP);           // [32][KNN_CAP]
+    int *gmin = reinterpret_cast<int *>(lds + WAVES * (32 * PITCH + 32));   // [KNN_G][NQ] keys
+    float *tau = reinterpret_cast<float *>(gmin + KNN_G * NQ);              // [NQ]
+    int *cnt = reinterpret_cast<int *>(tau + NQ);                           // [NQ] (+ overflow flag at [NQ])
+    float *cand_d = reinterpret_cast<float *>(cnt + NQ + 32);               // [NQ][KNN_CAP]
+    int *cand_i = reinterpret_cast<int *>(cand_d + NQ * KNN_CAP);           // [NQ][KNN_CAP]
 
     const int b = by;
-    const int q0 = bx * 32;
+    const int q0 = bx * NQ;
     const float *bp = base + (size_t)b * N * CT;
-    const int qrow_i = min(q0 + l31, S - 1);
-    const float *qp = query + ((size_t)b * S + qrow_i) * CT;
 
-    // query operand: lane (j, half) holds q[j][2kk + half]; |q|^2 by the A2 model
-    float qv[CP / 2];
+    // query operands: lane (j, half) holds q[j][2kk + half] of every group; |q|^2 by the A2 model
+    float qv[QG][CP / 2];
+    float qn[QG];
 #pragma unroll
-    for (int kk = 0; kk < CP / 2; ++kk) qv[kk] = (2 * kk + half < CT) ? qp[2 * kk + half] : 0.f;
-    const float qn = sum_sq_model<CT>(qp, CT);
-
-    for (int i = tid; i < KNN_G * 32; i += NT_) gmin[i] = 0x7f800000;      // +inf key
-    if (tid < 33) cnt[tid] = 0;
-    __syncthreads();
+    for (int g = 0; g < QG; ++g) {
+        const int qrow_i = min(q0 + g * 32 + l31, S - 1);
+        const float *qp = query + ((size_t)b * S + qrow_i) * CT;
+#pragma unroll
+        for (int kk = 0; kk < CP / 2; ++kk) qv[g][kk] = (2 * kk + half < CT) ? qp[2 * kk + half] : 0.f;
+        qn[g] = sum_sq_model<CT>(qp, CT);
+    }
 
     const int ntiles = (N + 31) / 32;
+    float *cloud = reinterpret_cast<float *>(cand_i + NQ * KNN_CAP);        // RES: [ntiles*32][4] | norms [ntiles*32]
+    float *cnorm = cloud + (size_t)ntiles * 32 * 4;
+    if constexpr (RES) {
+        // coalesced read of the packed [N][3] rows, 8 loads in flight per lane (one at a time, the 24 rounds of a
+        // 2048-point cloud are 24 global round trips: longer than both passes over the resident cloud)
+        const int total = ntiles * 32 * 3;
+        for (int j0 = tid; j0 < total; j0 += 8 * NT_) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 + u * NT_;
+                v[u] = j < 3 * N ? bp[j] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 + u * NT_;
+                if (j < total) cloud[j + j / 3] = v[u];             // 4 * (j / 3) + j % 3
+            }
+        }
+        for (int r = tid; r < ntiles * 32; r += NT_) cloud[4 * r + 3] = 0.f;
+    }
+    for (int i = tid; i < KNN_G * NQ; i += NT_) gmin[i] = 0x7f800000;      // +inf key
+    for (int i = tid; i < NQ + 1; i += NT_) cnt[i] = 0;
+    __syncthreads();
+    if constexpr (RES) {
+        for (int r = tid; r < ntiles * 32; r += NT_) cnorm[r] = r < N ? tile_row_norm<CT>(cloud + 4 * r) : INFINITY;
+        __syncthreads();
+    }
+
     float4 stg[CP >= 8 ? NV : 1];
     float stg3[2];
     constexpr bool PREFETCH = CT <= 64;          // wide rows: the staging registers are needed for qv
@@ -468,43 +516,71 @@ __device__ __forceinline__ void knn_mfma_body(const float *__restrict__ base, co
             *reinterpret_cast<float4 *>(slab + r * PITCH + 4 * c4) = i < lim ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    // one tile: stage, norms (A2 model; rows beyond N get +inf so they never qualify), MFMA chain
-    floatx16 acc;
+    // one tile: stage, norms (A2 model; rows beyond N get +inf so they never qualify), QG interleaved MFMA chains
+    floatx16 acc[QG];
+    float4 sn[4];
     auto tile_dots = [&](int t, bool first) {
-        if (PREFETCH) {
-            if (first) load_tile(t);
-            store_tile();
-            if (t + WAVES < ntiles) load_tile(t + WAVES);      // in flight during this tile's MFMAs
+        const float *row;
+        if constexpr (RES) {
+            row = cloud + (t * 32 + l31) * 4;
+            snorm = cnorm + t * 32;
         } else {
-            copy_tile(t);
+            if (PREFETCH) {
+                if (first) load_tile(t);
+                store_tile();
+                if (t + WAVES < ntiles) load_tile(t + WAVES);      // in flight during this tile's MFMAs
+            } else {
+                copy_tile(t);
+            }
+            __builtin_amdgcn_wave_barrier();
+            if constexpr (!GN) {
+                if (lane < 32) snorm[lane] = (t * 32 + lane < N) ? tile_row_norm<CT>(slab + lane * PITCH) : INFINITY;
+            }
+            row = slab + l31 * PITCH;
         }
+        // this lane's 16 base-row norms (rows (r & 3) + 8 (r >> 2) + 4 half of the tile) as four 16-byte reads issued
+        // BEFORE the MFMA chain: read one by one where they are used, every distance waited for its own LDS round
+        // trip (16 per tile and pass, ~100 clocks each -- more than the MFMAs of a C = 64 tile)
         __builtin_amdgcn_wave_barrier();
-        if (lane < 32) snorm[lane] = (t * 32 + lane < N) ? tile_row_norm<CT>(slab + lane * PITCH) : INFINITY;
+        if constexpr (GN) {
+            const float *gn = bnorm + (size_t)b * ntiles * 32 + t * 32 + 4 * half;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        const float *row = slab + l31 * PITCH;
+            for (int q4 = 0; q4 < 4; ++q4) sn[q4] = *reinterpret_cast<const float4 *>(gn + 8 * q4);
+        } else {
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) sn[q4] = *reinterpret_cast<const float4 *>(snorm + 8 * q4 + 4 * half);
+        }
+#pragma unroll
+        for (int g = 0; g < QG; ++g)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
 #pragma unroll
         for (int m = 0; m < CP / 4; ++m) {
             const float4 a = *reinterpret_cast<const float4 *>(row + 4 * m);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? a.y : a.x, qv[2 * m], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? a.w : a.z, qv[2 * m + 1], acc, 0, 0, 0);
+            const float a0 = half ? a.y : a.x, a1 = half ? a.w : a.z;
+#pragma unroll
+            for (int g = 0; g < QG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, qv[g][2 * m], acc[g], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < QG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, qv[g][2 * m + 1], acc[g], 0, 0, 0);
         }
         __builtin_amdgcn_wave_barrier();
     };
-#define KNN_DIST(r) ((-2.0f * acc[r] + qn) + snorm[((r) & 3) + 8 * ((r) >> 2) + 4 * half])
+#define KNN_DIST(g, r) ((-2.0f * acc[g][r] + qn[g]) + (&sn[(r) >> 2].x)[(r) & 3])
 
     bool fast = (ntiles * 8 >= K) && K <= KNN_CAP;
     if (fast) {
-        // ---------------- pass A: group minima.  Group g = (8t + 2qd + half) & 31 of query l31: with
+        // ---------------- pass A: group minima.  Group g = (8t + 2qd + half) & 31 of a query: with
         // tiles dealt t = wave, wave + WAVES, ... every group belongs to exactly one (wave, lane, qd,
         // t & 3), so the minima live in registers (LDS atomics retire ~1 lane per 2.5 clocks: 640
         // cycles per tile, against 2048 MFMA cycles at C = 64) and are stored once at the end.
         constexpr int TPH = 4 / WAVES;                      // distinct t & 3 values a wave sees
-        float gm[TPH][4];
+        float gm[QG][TPH][4];
 #pragma unroll
-        for (int a = 0; a < TPH; ++a)
+        for (int g = 0; g < QG; ++g)
 #pragma unroll
-            for (int qd = 0; qd < 4; ++qd) gm[a][qd] = INFINITY;
+            for (int a = 0; a < TPH; ++a)
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) gm[g][a][qd] = INFINITY;
         for (int t0 = wave, it = 0; t0 < ntiles; t0 += 4) {
 #pragma unroll
             for (int a = 0; a < TPH; ++a) {
@@ -513,59 +589,68 @@ __device__ __forceinline__ void knn_mfma_body(const float *__restrict__ base, co
                     tile_dots(t, it == 0);
                     ++it;
 #pragma unroll
-                    for (int qd = 0; qd < 4; ++qd) {
-                        const float m = fminf(fminf(KNN_DIST(4 * qd), KNN_DIST(4 * qd + 1)),
-                                              fminf(KNN_DIST(4 * qd + 2), KNN_DIST(4 * qd + 3)));
-                        gm[a][qd] = fminf(gm[a][qd], m);
-                    }
+                    for (int g = 0; g < QG; ++g)
+#pragma unroll
+                        for (int qd = 0; qd < 4; ++qd) {
+                            const float m = fminf(fminf(KNN_DIST(g, 4 * qd), KNN_DIST(g, 4 * qd + 1)),
+                                                  fminf(KNN_DIST(g, 4 * qd + 2), KNN_DIST(g, 4 * qd + 3)));
+                            gm[g][a][qd] = fminf(gm[g][a][qd], m);
+                        }
                     __builtin_amdgcn_wave_barrier();
                 }
             }
         }
 #pragma unroll
-        for (int a = 0; a < TPH; ++a)
+        for (int g = 0; g < QG; ++g)
 #pragma unroll
-            for (int qd = 0; qd < 4; ++qd) {
-                const int g = (((wave + a * WAVES) & 3) * 8 + qd * 2 + half) & (KNN_G - 1);
-                gmin[g * 32 + l31] = f2key(gm[a][qd]);
-            }
+            for (int a = 0; a < TPH; ++a)
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    const int grp = (((wave + a * WAVES) & 3) * 8 + qd * 2 + half) & (KNN_G - 1);
+                    gmin[grp * NQ + g * 32 + l31] = f2key(gm[g][a][qd]);
+                }
         __syncthreads();
         // tau[q] = K-th smallest group minimum (rank by (key, group))
-        for (int item = tid; item < 32 * KNN_G; item += NT_) {
-            const int q = item & 31, g = item >> 5;
-            const int v = gmin[g * 32 + q];
+        for (int item = tid; item < NQ * KNN_G; item += NT_) {
+            const int q = item % NQ, grp = item / NQ;
+            const int v = gmin[grp * NQ + q];
             int rank = 0;
             for (int o = 0; o < KNN_G; ++o) {
-                const int u = gmin[o * 32 + q];
-                rank += (u < v || (u == v && o < g)) ? 1 : 0;
+                const int u = gmin[o * NQ + q];
+                rank += (u < v || (u == v && o < grp)) ? 1 : 0;
             }
             if (rank == K - 1) tau[q] = __int_as_float(v >= 0 ? v : v ^ 0x7fffffff);
         }
         __syncthreads();
         // ---------------- pass B: collect d <= tau
-        const float tq = tau[l31];
+        float tq[QG];
+#pragma unroll
+        for (int g = 0; g < QG; ++g) tq[g] = tau[g * 32 + l31];
         for (int t = wave, it = 0; t < ntiles; t += WAVES, ++it) {
             tile_dots(t, it == 0);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float d = KNN_DIST(r);
-                const int n = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (d <= tq && n < N) {
-                    const int slot = atomicAdd(cnt + l31, 1);
-                    if (slot < KNN_CAP) {
-                        cand_d[l31 * KNN_CAP + slot] = d;
-                        cand_i[l31 * KNN_CAP + slot] = n;
-                    } else {
-                        cnt[32] = 1;                 // overflow: redo this workgroup the slow way
+            for (int g = 0; g < QG; ++g)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float d = KNN_DIST(g, r);
+                    const int n = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (d <= tq[g] && n < N) {
+                        const int ql = g * 32 + l31;
+                        const int slot = atomicAdd(cnt + ql, 1);
+                        if (slot < KNN_CAP) {
+                            cand_d[ql * KNN_CAP + slot] = d;
+                            cand_i[ql * KNN_CAP + slot] = n;
+                        } else {
+                            cnt[NQ] = 1;                 // overflow: redo this workgroup the slow way
+                        }
                     }
                 }
-            }
             __builtin_amdgcn_wave_barrier();
         }
         __syncthreads();
-        fast = cnt[32] == 0;
+        fast = cnt[NQ] == 0;
         if (fast) {
-            for (int item = tid; item < 32 * KNN_CAP; item += NT_) {
+            for (int item = tid; item < NQ * KNN_CAP; item += NT_) {
                 const int q = item / KNN_CAP, sl = item - q * KNN_CAP;
                 const int n_q = cnt[q];
                 if (sl < n_q && q0 + q < S) {
@@ -586,62 +671,88 @@ __device__ __forceinline__ void knn_mfma_body(const float *__restrict__ base, co
         __syncthreads();
     }
 
-    // ---------------- slow path: per-lane sorted lists (two half-lists per query and wave)
-    float bd[KMAX];
-    int bi[KMAX];
-#pragma unroll
-    for (int k = 0; k < KMAX; ++k) { bd[k] = INFINITY; bi[k] = 0; }
-    for (int t = wave, it = 0; t < ntiles; t += WAVES, ++it) {
-        tile_dots(t, it == 0);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float d = KNN_DIST(r);
-            if (d < bd[KMAX - 1]) list_insert<KMAX>(bd, bi, d, t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half);
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-#undef KNN_DIST
-    // merge the 2*WAVES sorted partial lists of every query: every lane ranks its own elements in
-    // the union (own position + lexicographically smaller pairs in each other list)
-    __syncthreads();
+    // ---------------- slow path: per-lane sorted lists (two half-lists per query and wave), one query group at a
+    // time (the tiles are recomputed per group: rare -- massive ties or K beyond the candidate lists)
     constexpr int NL = 2 * WAVES;
     float *cd = lds;                                              // [32][NL][KMAX]
     int *ci = reinterpret_cast<int *>(lds + 32 * NL * KMAX);
     const int list = wave * 2 + half;
+    auto slow_group = [&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        float bd[KMAX];
+        int bi[KMAX];
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k) {
-        cd[(l31 * NL + list) * KMAX + k] = bd[k];
-        ci[(l31 * NL + list) * KMAX + k] = bi[k];
-    }
-    __syncthreads();
-    if (q0 + l31 < S) {
-        const size_t o = ((size_t)b * S + q0 + l31) * K;
+        for (int k = 0; k < KMAX; ++k) { bd[k] = INFINITY; bi[k] = 0; }
+        for (int t = wave, it = 0; t < ntiles; t += WAVES, ++it) {
+            tile_dots(t, it == 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float d = KNN_DIST(g, r);
+                if (d < bd[KMAX - 1]) list_insert<KMAX>(bd, bi, d, t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        // merge the 2*WAVES sorted partial lists of every query: every lane ranks its own elements in
+        // the union (own position + lexicographically smaller pairs in each other list)
+        __syncthreads();
 #pragma unroll
         for (int k = 0; k < KMAX; ++k) {
-            const float d = bd[k];
-            const int n = bi[k];
-            int rank = k;
-            for (int ol = 0; ol < NL; ++ol) {
-                if (ol == list) continue;
-                for (int e = 0; e < KMAX; ++e)
-                    rank += lex_less(cd[(l31 * NL + ol) * KMAX + e], ci[(l31 * NL + ol) * KMAX + e], d, n) ? 1 : 0;
-            }
-            if (rank < K && d < INFINITY) {
-                out_idx[o + rank] = n;
-                if (out_dist) out_dist[o + rank] = d;
+            cd[(l31 * NL + list) * KMAX + k] = bd[k];
+            ci[(l31 * NL + list) * KMAX + k] = bi[k];
+        }
+        __syncthreads();
+        if (q0 + g * 32 + l31 < S) {
+            const size_t o = ((size_t)b * S + q0 + g * 32 + l31) * K;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                const float d = bd[k];
+                const int n = bi[k];
+                int rank = k;
+                for (int ol = 0; ol < NL; ++ol) {
+                    if (ol == list) continue;
+                    for (int e = 0; e < KMAX; ++e)
+                        rank += lex_less(cd[(l31 * NL + ol) * KMAX + e], ci[(l31 * NL + ol) * KMAX + e], d, n) ? 1 : 0;
+                }
+                if (rank < K && d < INFINITY) {
+                    out_idx[o + rank] = n;
+                    if (out_dist) out_dist[o + rank] = d;
+                }
             }
         }
+        __syncthreads();                                          // the lists alias the slabs of the next group's tiles
+    };
+    slow_group(std::integral_constant<int, 0>{});
+    if constexpr (QG > 1) slow_group(std::integral_constant<int, 1>{});
+    if constexpr (QG > 2) {
+        slow_group(std::integral_constant<int, 2>{});
+        slow_group(std::integral_constant<int, 3>{});
     }
+    static_assert(QG == 1 || QG == 2 || QG == 4, "query groups per workgroup");
+#undef KNN_DIST
 }
 
-template <int CT, int WAVES, int KMAX>
+template <int CT, int WAVES, int KMAX, int QG, bool RES, bool GN>
 __global__ __launch_bounds__(WAVES * 64) void knn_mfma_kernel(const float *__restrict__ base,
                                                               const float *__restrict__ query, int N, int S, int K,
                                                               float *__restrict__ out_dist,
-                                                              int64_t *__restrict__ out_idx)
+                                                              int64_t *__restrict__ out_idx,
+                                                              const float *__restrict__ bnorm)
 {
     extern __shared__ float lds[];
-    knn_mfma_body<CT, WAVES, KMAX>(base, query, N, S, K, out_dist, out_idx, blockIdx.x, blockIdx.y, lds);
+    knn_mfma_body<CT, WAVES, KMAX, QG, RES, GN>(base, query, N, S, K, out_dist, out_idx, blockIdx.x, blockIdx.y, lds, bnorm);
+}
+
+// Squared norms of rows [B][N][C] by the A2 rounding model -> out [B][ceil32(N)], +inf in the padding: computed once
+// per search instead of once per (query workgroup, pass, tile).
+template <int CT>
+__global__ __launch_bounds__(256) void row_norms_kernel(const float *__restrict__ x, int N, int npad, int C,
+                                                        float *__restrict__ out)
+{
+    const int b = blockIdx.y;
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= npad) return;
+    const int c_ = CT > 0 ? CT : C;
+    out[(size_t)b * npad + r] = r < N ? sum_sq_model<CT>(x + ((size_t)b * N + r) * c_, c_) : INFINITY;
 }
 
 // Farthest point sampling of one point-set state and the xyz-space kNN of the state before it in ONE
@@ -661,38 +772,63 @@ __global__ __launch_bounds__(256) void fps_knn3_kernel(const float *__restrict__
         fps_body<4, P>(fxyz, fN, fS, start, f_idx, f_out_xyz, blockIdx.x, lds);
     } else {
         const int r = blockIdx.x - B, qb = (S + 31) / 32;
-        knn_mfma_body<3, 4, 8>(base, query, N, S, K, out_dist, out_idx, r % qb, r / qb, lds);
+        knn_mfma_body<3, 4, 8, 1, false, false>(base, query, N, S, K, out_dist, out_idx, r % qb, r / qb, lds);
     }
 }
 
-template <int CT, int WAVES, int KMAX>
+template <int CT, int WAVES, int KMAX, int QG, bool RES = false, bool GN = false>
 int launch_knn_mfma(const float *base, const float *query, int B, int N, int S, int K, float *od, int64_t *oi,
-                    hipStream_t st)
+                    hipStream_t st, const float *bnorm = nullptr)
 {
     constexpr int CP = (CT + 3) & ~3;
-    constexpr size_t work = ((size_t)WAVES * (32 * (CP + 4) + 32) + KNN_G * 32 + 32 + 64 + 2 * 32 * KNN_CAP) *
+    constexpr int NQ = 32 * QG;
+    constexpr size_t work = ((size_t)WAVES * (32 * (CP + 4) + 32) + KNN_G * NQ + NQ + NQ + 32 + 2 * NQ * KNN_CAP) *
                             sizeof(float);
     constexpr size_t merge = (size_t)32 * 2 * WAVES * KMAX * 8;
-    constexpr size_t lds = work > merge ? work : merge;
-    static_assert(lds <= 160 * 1024, "LDS of a gfx950 CU");
-    if (lds > 64 * 1024) {
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_mfma_kernel<CT, WAVES, KMAX>),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static_assert(!RES || merge <= work, "the slow path's lists must not reach the resident cloud");
+    constexpr size_t fixed = work > merge ? work : merge;
+    constexpr size_t most = fixed + (RES ? (size_t)KNN_RES_MAX * 5 * sizeof(float) : 0);
+    static_assert(most <= 160 * 1024, "LDS of a gfx950 CU");
+    if (RES && N > KNN_RES_MAX) return MPA_EINVAL;
+    const size_t lds = fixed + (RES ? (size_t)mpa_ceil_div(N, 32) * 32 * 5 * sizeof(float) : 0);
+    if (most > 64 * 1024) {
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_mfma_kernel<CT, WAVES, KMAX, QG, RES, GN>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)most);
         if (attr != hipSuccess) return MPA_EHIP;
     }
-    dim3 grid(mpa_ceil_div(S, 32), B);
-    hipLaunchKernelGGL((knn_mfma_kernel<CT, WAVES, KMAX>), grid, dim3(WAVES * 64), lds, st, base, query, N, S, K, od,
-                       oi);
+    dim3 grid(mpa_ceil_div(S, NQ), B);
+    hipLaunchKernelGGL((knn_mfma_kernel<CT, WAVES, KMAX, QG, RES, GN>), grid, dim3(WAVES * 64), lds, st, base, query, N, S, K,
+                       od, oi, bnorm);
     MPA_LAUNCH_CHECK();
     return MPA_OK;
 }
 
-template <int CT, int WAVES>
+// QGMAX: the widest query grouping the channel count leaves registers for; used when the launch still has >= 4
+// workgroups per CU with it (the fine states), otherwise one group per workgroup keeps more waves in flight.
+template <int CT, int WAVES, int QGMAX = 1>
 int launch_knn_mfma_k(const float *base, const float *query, int B, int N, int S, int K, float *od, int64_t *oi,
-                      hipStream_t st)
+                      hipStream_t st, const float *bnorm = nullptr)
 {
-    if (K <= 8) return launch_knn_mfma<CT, WAVES, 8>(base, query, B, N, S, K, od, oi, st);
-    return launch_knn_mfma<CT, WAVES, 32>(base, query, B, N, S, K, od, oi, st);
+    if constexpr (CT == 3) {
+        static const bool no_res = getenv("MPA_KNN_NO_RESIDENT") != nullptr;
+        if (K <= 8 && N <= KNN_RES_MAX && !no_res)
+            return launch_knn_mfma<CT, WAVES, 8, 1, true>(base, query, B, N, S, K, od, oi, st);
+    } else {
+        // with the base norms given (K <= 8: every search of the models): QGMAX query groups per workgroup when the
+        // launch still has >= 2 workgroups per CU with them (the fine states), one group otherwise
+        if (bnorm != nullptr && K <= 8) {
+            static const int force_qg = getenv("MPA_KNN_QG") ? atoi(getenv("MPA_KNN_QG")) : 0;
+            const long long wgs1 = (long long)mpa_ceil_div(S, 32) * B;
+            bool wide = QGMAX > 1 && wgs1 >= 1024LL * QGMAX / 2;
+            if (force_qg) wide = QGMAX > 1 && force_qg > 1;
+            if constexpr (QGMAX > 1) {
+                if (wide) return launch_knn_mfma<CT, WAVES, 8, QGMAX, false, true>(base, query, B, N, S, K, od, oi, st, bnorm);
+            }
+            return launch_knn_mfma<CT, WAVES, 8, 1, false, true>(base, query, B, N, S, K, od, oi, st, bnorm);
+        }
+    }
+    if (K <= 8) return launch_knn_mfma<CT, WAVES, 8, 1>(base, query, B, N, S, K, od, oi, st);
+    return launch_knn_mfma<CT, WAVES, 32, 1>(base, query, B, N, S, K, od, oi, st);
 }
 
 int pick_tb(int C, int N, bool query_in_lds)
@@ -758,8 +894,8 @@ int launch_ball(const float *base, const float *query, int B, int N, int S, int 
 
 }  // namespace
 
-extern "C" int mpa_knn_f32(const float *base, const float *query, int B, int N, int S, int C, int K,
-                           float *out_dist, int64_t *out_idx, void *stream)
+static int knn_any(const float *base, const float *base_norms, const float *query, int B, int N, int S, int C, int K,
+                   float *out_dist, int64_t *out_idx, void *stream)
 {
     MPA_CLEAR_ERROR();
     if (!base || !query || !out_idx || B <= 0 || N <= 0 || S <= 0 || C <= 0 || K <= 0) return MPA_EINVAL;
@@ -770,13 +906,13 @@ extern "C" int mpa_knn_f32(const float *base, const float *query, int B, int N, 
     const bool scalar_path = getenv("MPA_KNN_SCALAR") != nullptr;       // development: the VALU kernel
     if (!scalar_path && (C == 3 || al16)) {
         switch (C) {                                                    // matrix-core kernel
-        case 3: return launch_knn_mfma_k<3, 4>(base, query, B, N, S, K, out_dist, out_idx, st);
-        case 32: return launch_knn_mfma_k<32, 4>(base, query, B, N, S, K, out_dist, out_idx, st);
-        case 64: return launch_knn_mfma_k<64, 4>(base, query, B, N, S, K, out_dist, out_idx, st);
+        case 3: return launch_knn_mfma_k<3, 4, 1>(base, query, B, N, S, K, out_dist, out_idx, st);
+        case 32: return launch_knn_mfma_k<32, 4, 2>(base, query, B, N, S, K, out_dist, out_idx, st, base_norms);
+        case 64: return launch_knn_mfma_k<64, 4, 2>(base, query, B, N, S, K, out_dist, out_idx, st, base_norms);
         // wide rows: the few (S/32)*B workgroups are latency bound on staging their base tiles, so the
         // tiles are dealt to more waves (one 33 KB / 17 KB slab each: past the 64 KB default)
-        case 128: return launch_knn_mfma_k<128, 4>(base, query, B, N, S, K, out_dist, out_idx, st);
-        case 256: return launch_knn_mfma_k<256, 2>(base, query, B, N, S, K, out_dist, out_idx, st);
+        case 128: return launch_knn_mfma_k<128, 4>(base, query, B, N, S, K, out_dist, out_idx, st, base_norms);
+        case 256: return launch_knn_mfma_k<256, 2>(base, query, B, N, S, K, out_dist, out_idx, st, base_norms);
         default: break;
         }
     }
@@ -785,6 +921,38 @@ extern "C" int mpa_knn_f32(const float *base, const float *query, int B, int N, 
     case 64: return launch_knn_k<64>(base, query, B, N, S, C, K, out_dist, out_idx, st);
     default: return launch_knn_k<0>(base, query, B, N, S, C, K, out_dist, out_idx, st);
     }
+}
+
+extern "C" int mpa_knn_f32(const float *base, const float *query, int B, int N, int S, int C, int K,
+                           float *out_dist, int64_t *out_idx, void *stream)
+{
+    return knn_any(base, nullptr, query, B, N, S, C, K, out_dist, out_idx, stream);
+}
+
+extern "C" int mpa_row_norms_f32(const float *x, int B, int N, int C, float *norms, void *stream)
+{
+    MPA_CLEAR_ERROR();
+    if (!x || !norms || B <= 0 || N <= 0 || C <= 0 || B > 65535) return MPA_EINVAL;
+    if (C >= 8 && (C & 7)) return MPA_EUNSUPPORTED;
+    const int npad = mpa_ceil_div(N, 32) * 32;
+    const dim3 grid(mpa_ceil_div(npad, 256), B);
+    hipStream_t st = (hipStream_t)stream;
+    switch (C) {
+    case 32: hipLaunchKernelGGL(row_norms_kernel<32>, grid, dim3(256), 0, st, x, N, npad, C, norms); break;
+    case 64: hipLaunchKernelGGL(row_norms_kernel<64>, grid, dim3(256), 0, st, x, N, npad, C, norms); break;
+    case 128: hipLaunchKernelGGL(row_norms_kernel<128>, grid, dim3(256), 0, st, x, N, npad, C, norms); break;
+    case 256: hipLaunchKernelGGL(row_norms_kernel<256>, grid, dim3(256), 0, st, x, N, npad, C, norms); break;
+    default: hipLaunchKernelGGL(row_norms_kernel<0>, grid, dim3(256), 0, st, x, N, npad, C, norms); break;
+    }
+    MPA_LAUNCH_CHECK();
+    return MPA_OK;
+}
+
+extern "C" int mpa_knn_norms_f32(const float *base, const float *base_norms, const float *query, int B, int N, int S,
+                                 int C, int K, float *out_dist, int64_t *out_idx, void *stream)
+{
+    if (!base_norms || ((uintptr_t)base_norms & 15) != 0) return MPA_EINVAL;
+    return knn_any(base, base_norms, query, B, N, S, C, K, out_dist, out_idx, stream);
 }
 
 extern "C" int mpa_fps_f32(const float *xyz, int B, int N, int S, const int64_t *start_idx, int64_t *out_idx,

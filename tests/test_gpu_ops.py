@@ -418,3 +418,31 @@ def test_grouped_weight_gradients_vs_torch(ops):
         # operands are multiples of 1/4 and 1/2 with small magnitudes: every partial sum is exact in fp32
         assert torch.equal(q[4].double(), w), (M, N, K)
         assert torch.equal(q[8].double(), ws), (M, N, K)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,S,N,C", [(32, 1024, 1000, 64), (40, 800, 333, 32), (2, 96, 130, 128), (3, 64, 77, 256)])
+def test_knn_wide_groups_and_given_norms_vs_oracle(ops, co, B, S, N, C):
+    """The two fast forms of the MFMA search against the C oracle, bit for bit: (i) >= 1024 workgroups of 32 queries
+    -> two query groups per workgroup (C = 32 / 64), (ii) base-row norms computed once by mpa_row_norms_f32 and handed
+    to mpa_knn_norms_f32 (what ops.knn_point does for C in {32,64,128,256}); ragged N (padding rows carry +inf)."""
+    from mpa_amd._lib import lib, check
+    base = randn((B, N, C), seed=N + C).cuda()
+    query = randn((B, S, C), seed=S + C, scale=0.7).cuda()
+    K = 8
+    od, oi = co.knn_point(K, base.cpu().numpy(), query.cpu().numpy())
+    dist, idx = ops.knn_point(K, base, query)                       # (ii) through the op
+    assert np.array_equal(idx.cpu().numpy(), oi)
+    assert np.array_equal(bits(dist.cpu().numpy()), bits(od))
+    dist1 = torch.empty_like(dist)
+    idx1 = torch.empty_like(idx)
+    st = torch.cuda.current_stream().cuda_stream
+    check(lib.mpa_knn_f32(base.data_ptr(), query.data_ptr(), B, N, S, C, K, dist1.data_ptr(), idx1.data_ptr(), st),
+          "mpa_knn_f32")                                            # norms recomputed inside the search
+    assert torch.equal(idx1, idx) and torch.equal(dist1, dist)
+    norms = torch.empty(B, (N + 31) // 32 * 32, device="cuda")
+    check(lib.mpa_row_norms_f32(base.data_ptr(), B, N, C, norms.data_ptr(), st), "mpa_row_norms_f32")
+    want = torch.from_numpy(co.row_norms(base.cpu().numpy())) if hasattr(co, "row_norms") else None
+    assert torch.isinf(norms[:, N:]).all()
+    if want is not None:
+        assert np.array_equal(bits(norms[:, :N].cpu().numpy()), bits(want.numpy()))
