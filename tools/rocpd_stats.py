@@ -1,5 +1,7 @@
-"""Kernel statistics (name, calls, total / average duration) from a rocprofv3 rocpd database, restricted to the
-LAST `--steps` replays when --per-step N is given (total / N).  Usage: rocpd_stats.py results.db [steps] [top]"""
+"""Kernel statistics (name, calls, total / average duration) from a rocprofv3 rocpd database.
+    rocpd_stats.py results.db [passes] [top]     whole run, totals divided by `passes`
+    rocpd_stats.py results.db last [top]         only the LAST replayed step (the kernels between the last two
+                                                 optimizer launches): what one HIP-graph replay of the step costs"""
 import re
 import sqlite3
 import sys
@@ -13,12 +15,21 @@ def short(name):
 
 def main():
     db = sys.argv[1]
-    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    last = len(sys.argv) > 2 and sys.argv[2] == "last"
+    steps = 1 if last or len(sys.argv) <= 2 else int(sys.argv[2])
     top = int(sys.argv[3]) if len(sys.argv) > 3 else 45
     c = sqlite3.connect(db)
     cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
     name_col = "name" if "name" in cols else "kernel_name"
     rows = c.execute("select %s, start, end from kernels order by start" % name_col).fetchall()
+    if last:
+        idx = [i for i, r in enumerate(rows) if "adam_kernel" in r[0]]
+        g = idx[-1]
+        while g - 1 in idx:
+            g -= 1
+        prev = [i for i in idx if i < g][-1]
+        rows = rows[prev + 1:g]
+        print("last replayed step: %d launches, span %.3f ms" % (len(rows), (rows[-1][2] - rows[0][1]) / 1e6))
     agg = {}
     for n, s, e in rows:
         a = agg.setdefault(short(n), [0, 0])
