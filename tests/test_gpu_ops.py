@@ -446,3 +446,21 @@ def test_knn_wide_groups_and_given_norms_vs_oracle(ops, co, B, S, N, C):
     assert torch.isinf(norms[:, N:]).all()
     if want is not None:
         assert np.array_equal(bits(norms[:, :N].cpu().numpy()), bits(want.numpy()))
+
+
+@pytest.mark.gpu
+def test_xyz_knn_memo_hits_only_on_unchanged_coordinates(ops):
+    """Coordinate searches are remembered per (base, query) tensor pair: the same tensors return the same result
+    object, an in-place edit or another tensor of equal content searches again (and still agrees)."""
+    xyz = unit_cloud(2, 256, seed=5).cuda()
+    q = xyz[:, ::4].contiguous()
+    d0, i0 = ops.knn_point(8, xyz, q)
+    d1, i1 = ops.knn_point(8, xyz, q)
+    assert i1 is i0 and d1 is d0                                   # remembered
+    d2, i2 = ops.knn_point(8, xyz.clone(), q)                      # other storage, same content: fresh search
+    assert i2 is not i0 and torch.equal(i2, i0) and torch.equal(d2, d0)
+    xyz.mul_(2.0)                                                  # in-place edit: the version moves on
+    d3, i3 = ops.knn_point(8, xyz, q)
+    assert i3 is not i0
+    want_d, want_i = ops.knn_point(8, xyz.clone(), q)
+    assert torch.equal(i3, want_i) and torch.equal(d3, want_d)
