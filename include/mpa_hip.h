@@ -305,6 +305,11 @@ int mpa_upsample_mean_bwd_f32(const float *grad_out, const int64_t *knn_idx, con
                               int B, int S, int K, int Nf, int C, float *grad_points,
                               void *stream);
 
+/* Global max over the points of a state: out[b][c] = max_n x[b][n][c], arg[b][c] = the first row attaining it
+ * (`t.max(dim=1, keepdim=True)[0]` of the part-seg head, modules/pointnet2_utils.py:846-850), and its backward
+ * grad_x[b][n][c] = (n == arg[b][c]) ? grad_out[b][c] : 0 (fully written).  NaNs are never selected. */
+int mpa_max_points_fwd_f32(const float *x, int B, int N, int C, float *out, int *arg, void *stream);
+int mpa_max_points_bwd_f32(const float *grad_out, const int *arg, int B, int N, int C, float *grad_x, void *stream);
 /* ---- PointNetFeaturePropagation interpolation: modules/pointnet2_utils.py:899-906.
  * three_nn = mpa_knn_f32 with K = 3 (query = xyz1, base = xyz2).
  * out[b,n,:] = sum_j w_j * points2[b, idx[b,n,j], :],  w_j = (1/(d_j+1e-8)) / sum_j (1/(d_j+1e-8)). */
@@ -415,6 +420,8 @@ int mpa_upsample_mean_bwd_bf16(const mpa_bf16 *grad_out, const int64_t *knn_idx,
                                void *stream);
 int mpa_group_col_sum_bf16(const mpa_bf16 *x, int G, int R, int C, int ld, float *out, void *stream);
 int mpa_gemm_grouped_bf16(const MpaGemmProblem *problems, int count, int transB, int b_is_f32, void *stream);
+int mpa_max_points_fwd_bf16(const mpa_bf16 *x, int B, int N, int C, mpa_bf16 *out, int *arg, void *stream);
+int mpa_max_points_bwd_bf16(const mpa_bf16 *grad_out, const int *arg, int B, int N, int C, mpa_bf16 *grad_x, void *stream);
 int mpa_bn_group_fwd_bf16(const MpaBnUnit *units, int count, int sum_mode, void *stream);
 int mpa_bn_group_bwd_reduce_bf16(const MpaBnUnit *units, int count, void *stream);
 int mpa_bn_group_bwd_apply_bf16(const MpaBnUnit *units, int count, void *stream);

@@ -90,6 +90,8 @@ class BnUnit(ctypes.Structure):
 
 
 for _sfx in ("f32", "bf16"):
+    SIGNATURES["mpa_max_points_fwd_" + _sfx] = [_vp, _i, _i, _i, _vp, _vp, _vp]
+    SIGNATURES["mpa_max_points_bwd_" + _sfx] = [_vp, _vp, _i, _i, _i, _vp, _vp]
     SIGNATURES["mpa_bn_group_fwd_" + _sfx] = [ctypes.POINTER(BnUnit), _i, _i, _vp]
     SIGNATURES["mpa_bn_group_bwd_reduce_" + _sfx] = [ctypes.POINTER(BnUnit), _i, _vp]
     SIGNATURES["mpa_bn_group_bwd_apply_" + _sfx] = [ctypes.POINTER(BnUnit), _i, _vp]

@@ -391,6 +391,116 @@ extern "C" int mpa_upsample_mean_bwd_bf16(const mpa_bf16 *grad_out, const int64_
     return MPA_OK;
 }
 
+// ---- global max over the points of a state: out[b][c] = max_n x[b][n][c] with the first maximum's index
+// (`x.max(dim=1)` of the part-seg head, reference modules/pointnet2_utils.py:846-850).  torch's own reduction is a
+// multi-workgroup kernel that mis-replays under HIP-graph capture on this stack and had to be taken in two stages
+// (20 us each on [32,2048,64]); here a workgroup of 64 row lanes x 16 channel lanes owns 16 channels of a cloud, every
+// lane walks N/64 rows with 8 loads in flight and the 64 partial (value, row) pairs meet in LDS.  NaNs are never
+// selected (an all-NaN column returns -inf, row 0).
+namespace {
+constexpr int MAXP_RL = 64, MAXP_CL = 16;
+
+template <typename T>
+__global__ __launch_bounds__(MAXP_RL * MAXP_CL) void max_points_fwd_kernel(const T *__restrict__ x, int N, int C,
+                                                                           T *__restrict__ out, int *__restrict__ arg)
+{
+    __shared__ float sv[MAXP_RL][MAXP_CL];
+    __shared__ int si[MAXP_RL][MAXP_CL];
+    const int cl = threadIdx.x & (MAXP_CL - 1), rl = threadIdx.x / MAXP_CL;
+    const int b = blockIdx.y, c = blockIdx.x * MAXP_CL + cl;
+    float best = -INFINITY;
+    int bi = 0;
+    if (c < C) {
+        const T *p = x + (size_t)b * N * C + c;
+        int n = rl;
+        for (; n + 7 * MAXP_RL < N; n += 8 * MAXP_RL) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = mpa_ld1<T>(p + (size_t)(n + u * MAXP_RL) * C);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (v[u] > best) { best = v[u]; bi = n + u * MAXP_RL; }
+        }
+        for (; n < N; n += MAXP_RL) {
+            const float v = mpa_ld1<T>(p + (size_t)n * C);
+            if (v > best) { best = v; bi = n; }
+        }
+    }
+    sv[rl][cl] = best;
+    si[rl][cl] = bi;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        for (int r = 1; r < MAXP_RL; ++r) {
+            const float v = sv[r][cl];
+            const int i2 = si[r][cl];
+            if (v > best || (v == best && i2 < bi)) { best = v; bi = i2; }
+        }
+        mpa_st1<T>(out + (size_t)b * C + c, best);
+        arg[(size_t)b * C + c] = bi;
+    }
+}
+
+// grad_x[b][n][c] = (n == arg[b][c]) ? grad_out[b][c] : 0 -- the zero fill and the scatter in one pass.
+template <typename T>
+__global__ __launch_bounds__(256) void max_points_bwd_kernel(const T *__restrict__ g, const int *__restrict__ arg, int N,
+                                                             int C, long long total, T *__restrict__ gx)
+{
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const long long bn = i / C;
+        const int n = (int)(bn % N), b = (int)(bn / N);
+        const int a = arg[(size_t)b * C + c];
+        mpa_st1<T>(gx + i, a == n ? mpa_ld1<T>(g + (size_t)b * C + c) : 0.f);
+    }
+}
+
+template <typename T>
+int max_points_fwd_any(const T *x, int B, int N, int C, T *out, int *arg, void *stream)
+{
+    MPA_CLEAR_ERROR();
+    if (!x || !out || !arg || B <= 0 || N <= 0 || C <= 0 || B > 65535) return MPA_EINVAL;
+    hipLaunchKernelGGL(max_points_fwd_kernel<T>, dim3(mpa_ceil_div(C, MAXP_CL), B), dim3(MAXP_RL * MAXP_CL), 0,
+                       (hipStream_t)stream, x, N, C, out, arg);
+    MPA_LAUNCH_CHECK();
+    return MPA_OK;
+}
+
+template <typename T>
+int max_points_bwd_any(const T *g, const int *arg, int B, int N, int C, T *gx, void *stream)
+{
+    MPA_CLEAR_ERROR();
+    if (!g || !arg || !gx || B <= 0 || N <= 0 || C <= 0) return MPA_EINVAL;
+    const long long total = (long long)B * N * C;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(max_points_bwd_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, arg, N, C, total,
+                       gx);
+    MPA_LAUNCH_CHECK();
+    return MPA_OK;
+}
+}  // namespace
+
+extern "C" int mpa_max_points_fwd_f32(const float *x, int B, int N, int C, float *out, int *arg, void *stream)
+{
+    return max_points_fwd_any<float>(x, B, N, C, out, arg, stream);
+}
+extern "C" int mpa_max_points_fwd_bf16(const mpa_bf16 *x, int B, int N, int C, mpa_bf16 *out, int *arg, void *stream)
+{
+    return max_points_fwd_any<bf16_t>(reinterpret_cast<const bf16_t *>(x), B, N, C, reinterpret_cast<bf16_t *>(out), arg,
+                                      stream);
+}
+extern "C" int mpa_max_points_bwd_f32(const float *grad_out, const int *arg, int B, int N, int C, float *grad_x,
+                                      void *stream)
+{
+    return max_points_bwd_any<float>(grad_out, arg, B, N, C, grad_x, stream);
+}
+extern "C" int mpa_max_points_bwd_bf16(const mpa_bf16 *grad_out, const int *arg, int B, int N, int C, mpa_bf16 *grad_x,
+                                       void *stream)
+{
+    return max_points_bwd_any<bf16_t>(reinterpret_cast<const bf16_t *>(grad_out), arg, B, N, C,
+                                      reinterpret_cast<bf16_t *>(grad_x), stream);
+}
+
 extern "C" int mpa_three_interp_fwd_f32(const float *points2, const int64_t *idx, const float *dist, int B, int Nq,
                                         int Nb, int C, float *out, void *stream)
 {

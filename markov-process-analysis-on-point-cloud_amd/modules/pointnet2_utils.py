@@ -393,15 +393,11 @@ class Fuse(nn.Module):
 
 
 def _max_over_points(t):
-    """t.max(dim=1, keepdim=True)[0] for [B,N,C] (reference :846-850), taken in two stages of <= 64
-    points each when N allows.  Same values and the same (first-maximum) gradient routing; the
-    single-stage form makes torch pick its multi-workgroup reduction, whose result was wrong from
-    the second replay of a captured HIP graph on (garbage arg-max indices -> the backward's
-    scatter_ faulted); the staged form never leaves one workgroup per output."""
-    B, N, C = t.shape
-    if N > 64 and N % 64 == 0:
-        return t.view(B, N // 64, 64, C).max(dim=2)[0].max(dim=1, keepdim=True)[0]
-    return t.max(dim=1, keepdim=True)[0]
+    """t.max(dim=1, keepdim=True)[0] for [B,N,C] (reference :846-850) on this library's kernel (ops.max_over_points:
+    same values, gradient to the first maximum).  torch's single-stage form picks a multi-workgroup reduction whose
+    result was wrong from the second replay of a captured HIP graph on (garbage arg-max indices -> the backward's
+    scatter_ faulted; regression test test_max_over_points_under_graph_replay keeps the torch-only evidence)."""
+    return ops.max_over_points(t)
 
 
 class KeepHighResolutionModulePartSeg(nn.Module):

@@ -685,6 +685,37 @@ def three_interpolate(xyz1, xyz2, points2):
     return _ThreeInterp.apply(_f32(points2), idx, dist)
 
 
+class _MaxOverPoints(torch.autograd.Function):
+    """x [B,N,C] -> max over the points [B,1,C]; the gradient goes to the first row attaining the maximum."""
+
+    @staticmethod
+    def forward(ctx, x):
+        B, N, C = x.shape
+        out = torch.empty(B, 1, C, dtype=x.dtype, device=x.device)
+        arg = torch.empty(B, C, dtype=torch.int32, device=x.device)
+        _launch("mpa_max_points_fwd_" + _sfx(x), _p(x), B, N, C, _p(out), _p(arg), _stream())
+        ctx.save_for_backward(arg)
+        ctx.shape = (B, N, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (arg,) = ctx.saved_tensors
+        B, N, C = ctx.shape
+        g = g.contiguous()
+        gx = torch.empty(B, N, C, dtype=g.dtype, device=g.device)
+        _launch("mpa_max_points_bwd_" + _sfx(g), _p(g), _p(arg), B, N, C, _p(gx), _stream())
+        return gx
+
+
+def max_over_points(x):
+    """x.max(dim=1, keepdim=True)[0] for a [B,N,C] state (reference modules/pointnet2_utils.py:846-850): one launch
+    forward, one backward (zero fill and scatter fused).  torch's reduction mis-replays under HIP-graph capture here
+     and costs 2 x 20 us staged; ties go to the lowest row."""
+    _dev(x)
+    return _MaxOverPoints.apply(_feat(x))
+
+
 class _CatBroadcast(torch.autograd.Function):
     """cat((a [B,N,Ca], rows [B,1,Cr] broadcast over N), 2): per-point features next to per-cloud rows (the
     part-seg head: conv5(points) | global maxima | label embedding, reference modules/pointnet2_utils.py:846-856).

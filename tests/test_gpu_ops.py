@@ -464,3 +464,26 @@ def test_xyz_knn_memo_hits_only_on_unchanged_coordinates(ops):
     assert i3 is not i0
     want_d, want_i = ops.knn_point(8, xyz.clone(), q)
     assert torch.equal(i3, want_i) and torch.equal(d3, want_d)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,N,C,dtype", [(2, 2048, 64, torch.float32), (3, 130, 20, torch.float32), (1, 1, 7, torch.float32),
+                                         (2, 512, 256, torch.bfloat16), (2, 77, 24, torch.bfloat16)])
+def test_max_over_points_matches_torch(ops, B, N, C, dtype):
+    """ops.max_over_points == x.max(dim=1, keepdim=True)[0]: values exactly, the gradient routed to the first row
+    attaining the maximum (ties: lowest row), zeros elsewhere."""
+    g = torch.Generator().manual_seed(N + C)
+    x = torch.randn(B, N, C, generator=g).to(dtype)
+    if N > 4:
+        x[:, 3] = x.max(dim=1)[0]                     # a tie between row 3 and the original arg-max row of every column
+    x = x.cuda().requires_grad_(True)
+    out = ops.max_over_points(x)
+    want_v, want_i = x.detach().float().cpu().max(dim=1, keepdim=True)
+    assert out.shape == (B, 1, C) and out.dtype == dtype
+    assert torch.equal(out.float().cpu(), want_v)
+    w = torch.randn(B, 1, C, generator=g).to(dtype).cuda()
+    (out * w).sum().backward()
+    xc = x.detach().float().cpu()
+    first = (xc == want_v).float().argmax(dim=1, keepdim=True)          # first row equal to the maximum
+    want_g = torch.zeros(B, N, C).scatter_(1, first, w.float().cpu())
+    assert torch.equal(x.grad.float().cpu(), want_g)
