@@ -159,6 +159,52 @@ __global__ void upsample_bwd_kernel(const T *__restrict__ grad_out, const int64_
     }
 }
 
+// The same with a lane owning 4 consecutive channels of a coarse point: the K indices, their duplicate mask and
+// the K divisors are read once per lane (the scalar form re-reads the index row per channel and per duplicate test),
+// every gathered row arrives as one 8- / 16-byte load per lane, all K of them in flight together.
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_bwd_v4_kernel(const T *__restrict__ grad_out,
+                                                              const int64_t *__restrict__ knn,
+                                                              const float *__restrict__ cnt, int S, int K, int Nf, int C,
+                                                              long long total4, T *__restrict__ grad_points)
+{
+    constexpr int KM = 16;
+    const int c4n = C >> 2;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+        const long long bs = i / c4n;
+        const int c = (int)(i - bs * c4n) << 2;
+        const int b = (int)(bs / S);
+        const int64_t *row = knn + bs * K;
+        int n[KM];
+        float d[KM];
+        float4 g[KM];
+#pragma unroll
+        for (int k = 0; k < KM; ++k) n[k] = k < K ? (int)mpa_clamp_idx(row[k], Nf) : -1;
+#pragma unroll
+        for (int k = 0; k < KM; ++k) {
+            bool dup = false;
+#pragma unroll
+            for (int j = 0; j < k; ++j) dup |= (n[j] == n[k]);
+            if (dup) n[k] = -1;                          // a point listed twice contributes once (reference :44-46)
+        }
+#pragma unroll
+        for (int k = 0; k < KM; ++k)
+            if (n[k] >= 0) {
+                const long long src = (long long)b * Nf + n[k];
+                d[k] = cnt[src];
+                g[k] = mpa_ld4<T>(grad_out + src * C + c);
+            }
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < KM; ++k)
+            if (n[k] >= 0) {
+                const float dd = d[k] == 0.0f ? 1.0f : d[k];
+                acc.x += g[k].x / dd; acc.y += g[k].y / dd; acc.z += g[k].z / dd; acc.w += g[k].w / dd;
+            }
+        mpa_st4<T>(grad_points + bs * C + c, acc);
+    }
+}
+
 __device__ __forceinline__ void interp_weights(const float *d, float w[3])
 {
     float r0 = 1.0f / (d[0] + 1e-8f), r1 = 1.0f / (d[1] + 1e-8f), r2 = 1.0f / (d[2] + 1e-8f);
@@ -341,6 +387,12 @@ extern "C" int mpa_upsample_mean_bwd_f32(const float *grad_out, const int64_t *k
     if (!grad_out || !knn_idx || !cnt || !grad_points || B <= 0 || S <= 0 || K <= 0 || Nf <= 0 || C <= 0)
         return MPA_EINVAL;
     long long total = (long long)B * S * C;
+    if (K <= 16 && (C & 3) == 0 && ((((uintptr_t)grad_out | (uintptr_t)grad_points)) & 15) == 0) {
+        hipLaunchKernelGGL(upsample_bwd_v4_kernel<float>, dim3(grid_for(total / 4)), dim3(256), 0, (hipStream_t)stream,
+                           grad_out, knn_idx, cnt, S, K, Nf, C, total / 4, grad_points);
+        MPA_LAUNCH_CHECK();
+        return MPA_OK;
+    }
     hipLaunchKernelGGL(upsample_bwd_kernel<float>, dim3(grid_for(total)), dim3(TPB), 0, (hipStream_t)stream, grad_out,
                        knn_idx, cnt, S, K, Nf, C, total, grad_points);
     MPA_LAUNCH_CHECK();
@@ -384,6 +436,13 @@ extern "C" int mpa_upsample_mean_bwd_bf16(const mpa_bf16 *grad_out, const int64_
     if (!grad_out || !knn_idx || !cnt || !grad_points || B <= 0 || S <= 0 || K <= 0 || Nf <= 0 || C <= 0)
         return MPA_EINVAL;
     long long total = (long long)B * S * C;
+    if (K <= 16 && (C & 3) == 0 && ((((uintptr_t)grad_out | (uintptr_t)grad_points)) & 7) == 0) {
+        hipLaunchKernelGGL(upsample_bwd_v4_kernel<bf16_t>, dim3(grid_for(total / 4)), dim3(256), 0, (hipStream_t)stream,
+                           reinterpret_cast<const bf16_t *>(grad_out), knn_idx, cnt, S, K, Nf, C, total / 4,
+                           reinterpret_cast<bf16_t *>(grad_points));
+        MPA_LAUNCH_CHECK();
+        return MPA_OK;
+    }
     hipLaunchKernelGGL(upsample_bwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(TPB), 0, (hipStream_t)stream,
                        reinterpret_cast<const bf16_t *>(grad_out), knn_idx, cnt, S, K, Nf, C, total,
                        reinterpret_cast<bf16_t *>(grad_points));
