@@ -288,7 +288,8 @@ def main():
         step()
     torch.cuda.synchronize()
     log("rank %d: warm-up done" % rank)
-    timed = TIMED[dt]
+    timed = dict(TIMED[dt])
+    timed.update({"mpa_fps_knn_xyz_f32": None, "mpa_fps_f32": None})      # the sampling chain: reported as `fps`, not priced
     if a.eager:
         ops.enable_kernel_timing(list(timed))
     mdist.barrier()
@@ -341,10 +342,11 @@ def main():
             except (OSError, ValueError, KeyError):
                 pass
         peak_mfma = MFMA_F32_PEAK_TFLOPS if dt == "f32" else MFMA_BF16_PEAK_TFLOPS
+        n_timed_passes = a.steps if a.eager else min(a.steps, 10)
         kernels = []
         for name, bound in timed.items():
             r = kt.get(name)
-            if not r or not r["launches"]:
+            if bound is None or not r or not r["launches"]:
                 continue
             sec = r["ms"] / 1e3
             if bound == "hbm":
@@ -376,6 +378,17 @@ def main():
             "roofline": roof,
             "roofline_other_kernels": kernels[1:],
         }
+        fps_recs = [kt[n] for n in ("mpa_fps_knn_xyz_f32", "mpa_fps_f32") if kt.get(n) and kt[n]["launches"]]
+        if fps_recs:
+            # FPS is a chain of S dependent iterations per cloud (latency bound): iterations per second
+            # against the per-iteration floor of its structure (one s_barrier + four dependent LDS round trips, ~650
+            # clocks at 2.4 GHz).  The fused launches also carry the xyz search of the previous state.
+            its = sum(r["algo_units"] for r in fps_recs)
+            sec = sum(r["ms"] for r in fps_recs) / 1e3
+            floor_us = 0.27
+            line["fps"] = {"iterations_per_s_per_cloud": its / sec, "us_per_iteration": sec / its * 1e6,
+                           "floor_us_per_iteration": floor_us, "floor_over_measured": floor_us / (sec / its * 1e6),
+                           "iterations_per_step": its / n_timed_passes, "ms_per_step": sec * 1e3 / n_timed_passes}
         kn = kt.get("mpa_knn_f32")
         if kn and kn["launches"]:
             # SURVEY 8(d)'s unit for the grouping kernel: query x base-point distance evaluations (each over the

@@ -186,7 +186,7 @@ def fps_and_knn_xyz(fps_in, npoint, k, knn_base, knn_query, start_idx=None):
     dist = torch.empty(B, S, k, dtype=torch.float32, device=base.device)
     idx = torch.empty(B, S, k, dtype=torch.int64, device=base.device)
     _launch("mpa_fps_knn_xyz_f32", _p(fps_in), B, fN, npoint, _p(start), _p(fidx), _p(fxyz), _p(base), _p(query), N, S, k,
-            _p(dist), _p(idx), _stream())
+            _p(dist), _p(idx), _stream(), algo_units=npoint)          # units: serial FPS iterations of the launch
     _memo_put(base, query, k, dist, idx)
     return fidx, fxyz, dist, idx
 
@@ -206,7 +206,7 @@ def farthest_point_sample(xyz, npoint, cuda=False, start_idx=None, return_xyz=Fa
         _launch("mpa_fps_generic_f32", _p(xyz), B, N, C, npoint, _p(start), _p(out), _stream())
         return (out, index_points(xyz, out)) if return_xyz else out
     oxyz = torch.empty(B, npoint, 3, dtype=torch.float32, device=xyz.device) if return_xyz else None
-    _launch("mpa_fps_f32", _p(xyz), B, N, npoint, _p(start), _p(out), _p(oxyz), _stream())
+    _launch("mpa_fps_f32", _p(xyz), B, N, npoint, _p(start), _p(out), _p(oxyz), _stream(), algo_units=npoint)
     return (out, oxyz) if return_xyz else out
 
 
