@@ -43,21 +43,22 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int *wave_tot, int &t
 constexpr int CSR_QUEUE_MAX = 254;
 constexpr int CSR_QUEUE_INTS = CSR_QUEUE_MAX + 2;
 
-__global__ __launch_bounds__(CSR_TPB) void csr_build_kernel(const int64_t *__restrict__ idx, int N, int SK, int range,
-                                                             int *__restrict__ rowptr, int *__restrict__ entries,
-                                                             int *__restrict__ queue)
+// The workgroup body (bx = range index, by = cloud), shared by csr_build_kernel and by launches that carry the table
+// build next to independent work (the attention backward's first pass, diffattn.hip).
+__device__ __forceinline__ void csr_build_body(const int64_t *__restrict__ idx, int N, int SK, int range,
+                                               int *__restrict__ rowptr, int *__restrict__ entries,
+                                               int *__restrict__ queue, const int bx, const int by, int *csr_lds)
 {
-    extern __shared__ int csr_lds[];       // cnt[range] | pos[range]
     __shared__ int wave_tot[CSR_TPB / 64];
     constexpr int EPT = 32;                // entries per thread and chunk, all loads in flight at once
-    int *cnt = csr_lds, *pos = csr_lds + range;
-    const int b = blockIdx.y, tid = threadIdx.x;
-    const int r0 = blockIdx.x * range, r1 = min(N, r0 + range);
+    int *cnt = csr_lds, *pos = csr_lds + range;          // cnt[range] | pos[range]
+    const int b = by, tid = threadIdx.x;
+    const int r0 = bx * range, r1 = min(N, r0 + range);
     const int64_t *nb = idx + (size_t)b * SK;
     int *rp = rowptr + (size_t)b * (N + 1);
     int *en = entries + (size_t)b * SK;
     for (int r = tid; r < range; r += CSR_TPB) cnt[r] = 0;
-    if (queue != nullptr && blockIdx.x == 0)
+    if (queue != nullptr && bx == 0)
         for (int i = tid; i < CSR_QUEUE_INTS; i += CSR_TPB) queue[(size_t)b * CSR_QUEUE_INTS + i] = i < 2 ? 0 : -1;
     __syncthreads();
     int rr[EPT];
@@ -105,12 +106,26 @@ __global__ __launch_bounds__(CSR_TPB) void csr_build_kernel(const int64_t *__res
     }
 }
 
+__global__ __launch_bounds__(CSR_TPB) void csr_build_kernel(const int64_t *__restrict__ idx, int N, int SK, int range,
+                                                             int *__restrict__ rowptr, int *__restrict__ entries,
+                                                             int *__restrict__ queue)
+{
+    extern __shared__ int csr_dyn_lds[];
+    csr_build_body(idx, N, SK, range, rowptr, entries, queue, blockIdx.x, blockIdx.y, csr_dyn_lds);
+}
+
+// rows per workgroup of a build over B clouds of N rows: ~256 rows each, >= 256 workgroups in all
+inline int csr_range(int B, int N)
+{
+    int ranges = 1;
+    while (ranges < 64 && (N / ranges > 256 || B * ranges < 256) && N / (2 * ranges) >= 32) ranges <<= 1;
+    return (N + ranges - 1) / ranges;
+}
+
 inline void launch_csr_build(const int64_t *idx, int B, int N, int SK, int *rowptr, int *entries, hipStream_t st,
                              int *queue = nullptr)
 {
-    int ranges = 1;                                       // workgroups per cloud: ~256 rows each, >= 256 in all
-    while (ranges < 64 && (N / ranges > 256 || B * ranges < 256) && N / (2 * ranges) >= 32) ranges <<= 1;
-    const int range = (N + ranges - 1) / ranges;
+    const int range = csr_range(B, N);
     hipLaunchKernelGGL(csr_build_kernel, dim3(mpa_ceil_div(N, range), B), dim3(CSR_TPB),
                        (size_t)2 * range * sizeof(int), st, idx, N, SK, range, rowptr, entries, queue);
 }

@@ -253,16 +253,16 @@ __global__ __launch_bounds__(TPB) void diffattn_bwd_p1_kernel(
 }
 
 template <int K_, typename TF>
-__global__ __launch_bounds__(TPB) void diffattn_bwd_p1_v4_kernel(
+__device__ __forceinline__ void diffattn_bwd_p1_v4_body(
     const TF *__restrict__ q, const TF *__restrict__ kk, const TF *__restrict__ vv, int ldkv, int ldq,
     const int64_t *__restrict__ idx, const uint8_t *__restrict__ argk, const TF *__restrict__ gctx, int N, int S,
     int K, int C, float alpha, long long total4, TF *__restrict__ gq, TF *__restrict__ T,
-    TF *__restrict__ Tv)
+    TF *__restrict__ Tv, const int blk, const int nblk)
 {
     constexpr int KK = K_ > 0 ? K_ : KMAX;
     const int k_ = K_ > 0 ? K_ : K;
     const int c4n = C >> 2;
-    for (long long i = blockIdx.x * (long long)TPB + threadIdx.x; i < total4; i += (long long)gridDim.x * TPB) {
+    for (long long i = blk * (long long)TPB + threadIdx.x; i < total4; i += (long long)nblk * TPB) {
         const long long p = i / c4n;
         const int c = (int)(i - p * c4n) << 2;
         const int b = (int)(p / S);
@@ -322,6 +322,42 @@ __global__ __launch_bounds__(TPB) void diffattn_bwd_p1_v4_kernel(
         mpa_st4<TF>(gq + p * ldq + c, make_float4(dq4[0], dq4[1], dq4[2], dq4[3]));
         mpa_st4<TF>(Tv + p * C + c, make_float4(dv4[0], dv4[1], dv4[2], dv4[3]));
     }
+}
+
+template <int K_, typename TF>
+__global__ __launch_bounds__(TPB) void diffattn_bwd_p1_v4_kernel(
+    const TF *__restrict__ q, const TF *__restrict__ kk, const TF *__restrict__ vv, int ldkv, int ldq,
+    const int64_t *__restrict__ idx, const uint8_t *__restrict__ argk, const TF *__restrict__ gctx, int N, int S,
+    int K, int C, float alpha, long long total4, TF *__restrict__ gq, TF *__restrict__ T,
+    TF *__restrict__ Tv)
+{
+    diffattn_bwd_p1_v4_body<K_, TF>(q, kk, vv, ldkv, ldq, idx, argk, gctx, N, S, K, C, alpha, total4, gq, T, Tv, blockIdx.x,
+                                    gridDim.x);
+}
+
+// The first pass and the inverted-table build in ONE launch: the table depends on idx only and the first pass does
+// not read it (the second pass does), so the build's (ranges x B) workgroups ride along instead of costing a launch
+// of their own in front (8-14 us each, 10 per cls step / 16 per part-seg step).
+struct CsrArgs {
+    int N, SK, range, ranges, B;
+    int *rowptr, *entries, *queue;
+};
+template <int K_, typename TF>
+__global__ __launch_bounds__(TPB) void diffattn_bwd_p1_csr_kernel(
+    const TF *__restrict__ q, const TF *__restrict__ kk, const TF *__restrict__ vv, int ldkv, int ldq,
+    const int64_t *__restrict__ idx, const uint8_t *__restrict__ argk, const TF *__restrict__ gctx, int N, int S,
+    int K, int C, float alpha, long long total4, TF *__restrict__ gq, TF *__restrict__ T,
+    TF *__restrict__ Tv, CsrArgs ca)
+{
+    extern __shared__ int p1_csr_lds[];
+    const int csr_blocks = ca.ranges * ca.B;
+    if ((int)blockIdx.x < csr_blocks) {
+        csr_build_body(idx, ca.N, ca.SK, ca.range, ca.rowptr, ca.entries, ca.queue, blockIdx.x % ca.ranges,
+                       blockIdx.x / ca.ranges, p1_csr_lds);
+        return;
+    }
+    diffattn_bwd_p1_v4_body<K_, TF>(q, kk, vv, ldkv, ldq, idx, argk, gctx, N, S, K, C, alpha, total4, gq, T, Tv,
+                                    blockIdx.x - csr_blocks, gridDim.x - csr_blocks);
 }
 
 // lane = (base row, V channels); rows_per_block = 256 / lanes_per_row; blockIdx.y = cloud, so the
@@ -790,12 +826,22 @@ static int diffattn_bwd_any(const TF *q, int ldq, const TF *k, const TF *v, int 
         int *rowptr = reinterpret_cast<int *>((char *)workspace + w.rowptr_off);
         int *entries = reinterpret_cast<int *>((char *)workspace + w.entries_off);
         int *queue = reinterpret_cast<int *>((char *)workspace + w.queue_off);
-        launch_csr_build(idx, B, N, S * K, rowptr, entries, st, queue);
         static const bool scalar_only = getenv("MPA_DIFFATTN_SCALAR") != nullptr;
+        static const bool no_fuse = getenv("MPA_DIFFATTN_NO_CSR_FUSION") != nullptr;
         const bool p1v4 = (!scalar_only || !F32) && (C & 3) == 0 && (ldkv & 3) == 0 && (ldq & 3) == 0 &&
                           ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)grad_ctx | (uintptr_t)grad_q) &
                             mpa_vec4_align<TF>::mask) == 0) && (((uintptr_t)argk & 3) == 0);
-        if (p1v4 && K == 8)
+        const bool fused = p1v4 && K == 8 && !no_fuse;
+        if (!fused) launch_csr_build(idx, B, N, S * K, rowptr, entries, st, queue);
+        if (fused) {
+            CsrArgs ca;
+            ca.N = N; ca.SK = S * K; ca.range = csr_range(B, N); ca.ranges = mpa_ceil_div(N, ca.range); ca.B = B;
+            ca.rowptr = rowptr; ca.entries = entries; ca.queue = queue;
+            const int csr_blocks = ca.ranges * B;
+            hipLaunchKernelGGL((diffattn_bwd_p1_csr_kernel<8, TF>), dim3(csr_blocks + grid_for(total / 4)), dim3(TPB),
+                               (size_t)2 * ca.range * sizeof(int), st, q, k, v, ldkv, ldq, idx, argk, grad_ctx, N, S, K, C,
+                               alpha, total / 4, grad_q, T, Tv, ca);
+        } else if (p1v4 && K == 8)
             hipLaunchKernelGGL((diffattn_bwd_p1_v4_kernel<8, TF>), dim3(grid_for(total / 4)), dim3(TPB), 0, st, q, k, v, ldkv,
                                ldq, idx, argk, grad_ctx, N, S, K, C, alpha, total / 4, grad_q, T, Tv);
         else if (p1v4)
