@@ -71,6 +71,16 @@ int mpa_square_distance_f32(const float *src, const float *dst, int B, int S, in
  * C in {1..8, 16, 32, 64, 128, 256, 512}; K <= 32; K <= N. */
 int mpa_knn_f32(const float *base, const float *query, int B, int N, int S, int C, int K,
                 float *out_dist, int64_t *out_idx, void *stream);
+/* FPS of the NEXT state (fps_* as in mpa_fps_knn_xyz_f32), the coordinate search of THIS state (xyz_*: optional, pass
+ * xyz_base = NULL to skip) and its feature-space search (feat_*: as mpa_knn_f32 / mpa_knn_norms_f32, feat_norms optional)
+ * in ONE launch: the sampling keeps one workgroup per cloud busy for fps_S dependent iterations, the searches use the
+ * rest of the chip.  Results are those of the separate entry points bit for bit.  MPA_EUNSUPPORTED for shapes outside
+ * the instantiated set (fps_N in 129..2048, K <= 8, C in {64, 128}, 16-byte aligned rows): use the separate calls. */
+int mpa_fps_knn_feat_f32(const float *fps_xyz, int B, int fps_N, int fps_S, const int64_t *start_idx,
+                         int64_t *fps_idx, float *fps_out_xyz, const float *xyz_base, const float *xyz_query,
+                         int xN, int xS, int xK, float *xyz_dist, int64_t *xyz_idx, const float *feat_base,
+                         const float *feat_norms, const float *feat_query, int N, int S, int C, int K,
+                         float *out_dist, int64_t *out_idx, void *stream);
 /* The same search with the base rows' squared norms given: norms [B][ceil32(N)] from mpa_row_norms_f32 (the reference's
  * `torch.sum(dst ** 2, -1)`, modules/pointnet2_utils.py:207, rounded as there; +inf in the padding).  One small launch
  * computes them once per search instead of once per (32-query workgroup, pass, tile) inside it.  Results are identical

@@ -31,6 +31,8 @@ SIGNATURES = {
     "mpa_square_distance_f32": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "mpa_knn_f32": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp],
     "mpa_row_norms_f32": [_vp, _i, _i, _i, _vp, _vp],
+    "mpa_fps_knn_feat_f32": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i,
+                             _vp, _vp, _vp],
     "mpa_knn_norms_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp],
     "mpa_ball_query_f32": [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp],
     "mpa_gather_fwd_f32": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],

@@ -894,6 +894,7 @@ int launch_ball(const float *base, const float *query, int B, int N, int S, int 
 
 }  // namespace
 
+#ifndef MPA_KNN_BODIES_ONLY       // (knn_fused.hip includes this file for the device bodies above only)
 static int knn_any(const float *base, const float *base_norms, const float *query, int B, int N, int S, int C, int K,
                    float *out_dist, int64_t *out_idx, void *stream)
 {
@@ -1016,3 +1017,4 @@ extern "C" int mpa_square_distance_f32(const float *src, const float *dst, int B
     MPA_LAUNCH_CHECK();
     return MPA_OK;
 }
+#endif  // MPA_KNN_BODIES_ONLY

@@ -310,12 +310,18 @@ class LocalMerge(nn.Module):
     def forward(self, xyz, base_xyz, normal=None, feature=None, FPS_idx=None, xyz_flag=True, geometry=None):
         # `geometry` (optional, not in the reference signature): this level's precomputed
         # (dist, idx) of knn_point(self.knn, base_xyz, xyz) from ops.geometry_pass
-        dist, idx = knn_point(self.knn, base_xyz, xyz) if geometry is None else (geometry.dist, geometry.idx)
+        # `geometry`: a level of ops.GeometryChain -- it issues this state's searches together with the NEXT state's
+        # sampling (one launch: the FPS chain hides behind the feature-space search)
         if feature is None:
+            dist, idx = knn_point(self.knn, base_xyz, xyz) if geometry is None else geometry.xyz_search()
             merge_features = self.xyz_Trans(features=xyz, idx=idx, pos=base_xyz, FPS_idx=FPS_idx, xyz=True)
         else:
             fs = feature if FPS_idx is None else index_points(feature, FPS_idx)
-            _, idx_feature = knn_point(self.knn, feature, fs)
+            if geometry is None:
+                dist, idx = knn_point(self.knn, base_xyz, xyz)
+                _, idx_feature = knn_point(self.knn, feature, fs)
+            else:
+                (dist, idx), idx_feature = geometry.search(self.knn, feature, fs)
             merge_features = self.fc2(self._three_streams(base_xyz, feature, idx, idx_feature, FPS_idx, fs))
         if FPS_idx is not None:
             normal = index_points(normal, FPS_idx)
@@ -438,15 +444,21 @@ class KeepHighResolutionModulePartSeg(nn.Module):
         nrm = normal.permute(0, 2, 1).contiguous()
         N = x0.shape[1]
         # encoder: four FPS halvings, one LocalMerge per state.  The sampling chain and the xyz-space
-        # kNNs depend on the coordinates only: ops.geometry_pass issues them first, state i's search
+        # kNNs depend on the coordinates only: ops.GeometryChain advances them on demand, state i's searches
         # sharing a launch with state i+1's sampling (FPS start indices drawn in the reference's order)
-        geo_ = ops.geometry_pass(x0, (N // 2, N // 4, N // 8, N // 16), self.la0.knn)
-        g0, g1, g2, g3, g4 = (geo_.level(i) for i in range(5))
-        p0, x1, p1, x2, p2, x3, p3, x4 = g1.fps_idx, g1.xyz, g2.fps_idx, g2.xyz, g3.fps_idx, g3.xyz, g4.fps_idx, g4.xyz
-        e0, n0, k0, d0_ = self.la0(xyz=x0, base_xyz=x0, normal=nrm, xyz_flag=True, geometry=g0)
+        geo_ = ops.GeometryChain(x0, (N // 2, N // 4, N // 8, N // 16), self.la0.knn)
+        e0, n0, k0, d0_ = self.la0(xyz=x0, base_xyz=x0, normal=nrm, xyz_flag=True, geometry=geo_.level(0))
+        g1 = geo_.level(1)
+        p0, x1 = g1.fps_idx, g1.xyz
         e1, n1, k1, _ = self.la1(xyz=x1, base_xyz=x0, normal=n0, feature=e0, FPS_idx=p0, xyz_flag=True, geometry=g1)
+        g2 = geo_.level(2)
+        p1, x2 = g2.fps_idx, g2.xyz
         e2, n2, k2, _ = self.la2(xyz=x2, base_xyz=x1, normal=n1, feature=e1, FPS_idx=p1, xyz_flag=False, geometry=g2)
+        g3 = geo_.level(3)
+        p2, x3 = g3.fps_idx, g3.xyz
         e3, n3, k3, _ = self.la3(xyz=x3, base_xyz=x2, normal=n2, feature=e2, FPS_idx=p2, xyz_flag=True, geometry=g3)
+        g4 = geo_.level(4)
+        p3, x4 = g4.fps_idx, g4.xyz
         e4, n4, k4, _ = self.la4(xyz=x4, base_xyz=x3, normal=n3, feature=e3, FPS_idx=p3, xyz_flag=False, geometry=g4)
 
         geo = dict(FPS_0=p0, FPS_1=p1, FPS_2=p2, FPS_3=p3, knn_0=k0, knn_1=k1, knn_2=k2, knn_3=k3, knn_4=k4,

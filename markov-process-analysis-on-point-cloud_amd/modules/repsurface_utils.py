@@ -173,12 +173,18 @@ class LocalMerge(nn.Module):
     def forward(self, xyz, base_xyz, normal=None, feature=None, FPS_idx=None, xyz_flag=True, geometry=None):
         # `geometry` (optional, not in the reference signature): this level's precomputed
         # (dist, idx) of knn_point(self.knn, base_xyz, xyz) from ops.geometry_pass
-        dist, idx = knn_point(self.knn, base_xyz, xyz) if geometry is None else (geometry.dist, geometry.idx)
+        # `geometry`: a level of ops.GeometryChain -- it issues this state's searches together with the NEXT state's
+        # sampling (one launch: the FPS chain hides behind the feature-space search)
         if feature is None:
+            dist, idx = knn_point(self.knn, base_xyz, xyz) if geometry is None else geometry.xyz_search()
             merge_features = self.xyz_Trans(features=xyz, idx=idx, pos=base_xyz, FPS_idx=FPS_idx, xyz=True)
         else:
             fs = feature if FPS_idx is None else index_points(feature, FPS_idx)
-            _, idx_feature = knn_point(self.knn, feature, fs)
+            if geometry is None:
+                dist, idx = knn_point(self.knn, base_xyz, xyz)
+                _, idx_feature = knn_point(self.knn, feature, fs)
+            else:
+                (dist, idx), idx_feature = geometry.search(self.knn, feature, fs)
             merge_features = self.fc2(local_trans_pair(self.feature_Trans, self.feature_Trans2, feature, idx,
                                                        idx_feature, fs, concat=True))
         return merge_features, normal, idx, dist
@@ -213,10 +219,10 @@ class KeepHighResolutionModule(nn.Module):
     def forward(self, xyz, normal):
         xyz = xyz.permute(0, 2, 1).contiguous()
         normal = normal.permute(0, 2, 1).contiguous()
-        # Geometry pass: every FPS level and every xyz-space kNN depends on the input coordinates
-        # only (992 serial FPS iterations on 64 of the 256 CUs), so it runs ahead on a side stream
-        # while la0/la1 keep the rest of the chip busy; each level waits for its own event.
-        geo = ops.geometry_pass(xyz, self.LEVELS, self.la0.knn)
+        # Every FPS level and every xyz-space kNN depends on the input coordinates only (992 serial FPS
+        # iterations on 64 of the 256 CUs): the chain is advanced on demand, state i+1's sampling in the same
+        # launch as state i's searches, which keep the rest of the chip busy meanwhile.
+        geo = ops.GeometryChain(xyz, self.LEVELS, self.la0.knn)
         feat, normal, _, _ = self.la0(xyz=xyz, base_xyz=xyz, normal=normal, xyz_flag=True, geometry=geo.level(0))
         base = xyz
         for lvl, la in enumerate((self.la1, self.la2, self.la3, self.la4, self.la5), start=1):

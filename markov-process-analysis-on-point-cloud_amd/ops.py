@@ -346,7 +346,28 @@ def three_nn(xyz1, xyz2):
 
 # ------------------------------------------------------------------------------- geometry pass
 class _GeoLevel:
-    __slots__ = ("xyz", "fps_idx", "dist", "idx", "event")
+    """One point-set state of a forward pass: its coordinates, the FPS indices that selected it from the state before,
+    and its coordinate search (dist, idx) in that state.  Levels of a GeometryChain compute the search -- and the NEXT
+    state's sampling -- on demand (xyz_search / search); levels of a geometry_pass carry them precomputed."""
+    __slots__ = ("xyz", "fps_idx", "dist", "idx", "event", "chain", "i")
+
+    def __init__(self):
+        self.xyz = self.fps_idx = self.dist = self.idx = self.event = self.chain = None
+        self.i = 0
+
+    def xyz_search(self):
+        """(dist, idx) of knn_point(k, state before, this state) [level 0: itself in itself]."""
+        if self.idx is None:
+            self.chain._advance(self, None, None, None)
+        return self.dist, self.idx
+
+    def search(self, k, feature, query):
+        """((dist, idx) as xyz_search, idx_feature = knn_point(k, feature, query)[1]); a chain level issues the next
+        state's sampling, this coordinate search (if still due) and the feature search as one launch."""
+        if self.chain is None:
+            return (self.dist, self.idx), knn_point(k, feature, query)[1]
+        idx_f = self.chain._advance(self, k, feature, query)
+        return (self.dist, self.idx), idx_f
 
 
 class GeometryPass:
@@ -362,6 +383,112 @@ class GeometryPass:
             torch.cuda.current_stream().wait_event(g.event)
             g.event = None
         return g
+
+
+# The next state's FPS rides in the launch of this state's searches (mpa_fps_knn_feat_f32).  Off: the chain issues the
+# same work as separate launches (bench.py times kernels that way: one entry point per event bracket).
+FUSE_FPS_FEATURE_SEARCH = os.environ.get("MPA_NO_FPS_FEATURE_FUSION") is None
+
+
+def set_fps_feature_fusion(on):
+    global FUSE_FPS_FEATURE_SEARCH
+    old, FUSE_FPS_FEATURE_SEARCH = FUSE_FPS_FEATURE_SEARCH, bool(on)
+    return old
+
+
+def fps_knn_fused(fps_in, npoint, k_xyz, xyz_base, xyz_query, k_feat, feat_base, feat_query, start_idx=None):
+    """farthest_point_sample(fps_in, npoint, return_xyz=True), knn_point(k_xyz, xyz_base, xyz_query) (skipped when
+    xyz_base is None) and knn_point(k_feat, feat_base, feat_query) as ONE launch where the shapes allow (feature rows of
+    64 / 128 floats, k <= 8, 129..2048 points to sample from), otherwise as the separate launches.
+    -> (fps_idx, fps_xyz, (dist, idx) | None, (dist_f, idx_f)); every result equals the separate calls' bit for bit."""
+    _dev(fps_in, feat_base, feat_query)
+    fb, fq = _f32(feat_base.detach().float()), _f32(feat_query.detach().float())
+    B, N, C = fb.shape
+    S = fq.shape[1]
+    fN = fps_in.shape[1]
+    ok = (FUSE_FPS_FEATURE_SEARCH and C in (64, 128) and k_feat <= 8 and 128 < fN <= 2048 and fps_in.shape[2] == 3
+          and fb.data_ptr() % 16 == 0 and fq.data_ptr() % 16 == 0 and (xyz_base is None or k_xyz <= 8))
+    if not ok:
+        if xyz_base is not None:
+            fidx, fxyz, dx, ix = fps_and_knn_xyz(fps_in, npoint, k_xyz, xyz_base, xyz_query, start_idx=start_idx)
+            res_x = (dx, ix)
+        else:
+            fidx, fxyz = farthest_point_sample(fps_in, npoint, start_idx=start_idx, return_xyz=True)
+            res_x = None
+        return fidx, fxyz, res_x, knn_point(k_feat, fb, fq)
+    fin = _f32(fps_in.detach())
+    start = _fps_start(B, fN, fin.device, start_idx)
+    dev = fin.device
+    fidx = torch.empty(B, npoint, dtype=torch.int64, device=dev)
+    fxyz = torch.empty(B, npoint, 3, dtype=torch.float32, device=dev)
+    xb = xq = dx = ix = None
+    xN = xS = 0
+    if xyz_base is not None:
+        xb, xq = _f32(xyz_base.detach()), _f32(xyz_query.detach())
+        xN, xS = xb.shape[1], xq.shape[1]
+        dx = torch.empty(B, xS, k_xyz, dtype=torch.float32, device=dev)
+        ix = torch.empty(B, xS, k_xyz, dtype=torch.int64, device=dev)
+    df = torch.empty(B, S, k_feat, dtype=torch.float32, device=dev)
+    jf = torch.empty(B, S, k_feat, dtype=torch.int64, device=dev)
+    norms = None
+    if C == 64 and (S + 31) // 32 * B >= 1024:                   # the fine states: two query groups per workgroup
+        norms = torch.empty(B, (N + 31) // 32 * 32, dtype=torch.float32, device=dev)
+        _launch("mpa_row_norms_f32", _p(fb), B, N, C, _p(norms), _stream())
+    _launch("mpa_fps_knn_feat_f32", _p(fin), B, fN, npoint, _p(start), _p(fidx), _p(fxyz), _p(xb), _p(xq), xN, xS,
+            int(k_xyz or 0), _p(dx), _p(ix), _p(fb), _p(norms), _p(fq), N, S, C, k_feat, _p(df), _p(jf), _stream(),
+            algo_units=npoint)
+    if xb is not None:
+        _memo_put(xb, xq, k_xyz, dx, ix)
+    return fidx, fxyz, (None if xb is None else (dx, ix)), (df, jf)
+
+
+class GeometryChain:
+    """The sampling chain xyz -> npoints[0] -> npoints[1] ... of one forward pass, advanced on demand: level i's
+    coordinate search and state i+1's sampling are issued when la_i asks for its neighbourhoods, in the same launch as
+    la_i's feature-space search (level 0, which has no features: FPS + coordinate search).  FPS start indices are drawn
+    (or fed) in the reference's order (state 1, 2, ...)."""
+
+    def __init__(self, xyz, npoints, k):
+        _dev(xyz)
+        self.npoints, self.k = tuple(npoints), k
+        g = _GeoLevel()
+        g.xyz, g.chain, g.i = xyz, self, 0
+        self.levels = [g] + [None] * len(self.npoints)
+
+    def level(self, i):
+        g = self.levels[i]
+        if g is None:
+            raise RuntimeError("GeometryChain: state %d exists once state %d has been searched (LocalMerge order)" % (i, i - 1))
+        return g
+
+    def _advance(self, g, k_feat, feature, query):
+        """Issue whatever of (next state's FPS, this state's coordinate search, feature search) is still due."""
+        i, L = g.i, len(self.npoints)
+        base = self.levels[i - 1].xyz if i > 0 else g.xyz
+        need_xyz = g.idx is None
+        need_fps = i < L and self.levels[i + 1] is None
+        idx_f = None
+        with torch.no_grad():
+            if need_fps and feature is not None:
+                fidx, fxyz, rx, (_, idx_f) = fps_knn_fused(g.xyz, self.npoints[i], self.k, base if need_xyz else None,
+                                                           g.xyz if need_xyz else None, k_feat, feature, query)
+                if rx is not None:
+                    g.dist, g.idx = rx
+            elif need_fps:
+                if need_xyz:
+                    fidx, fxyz, g.dist, g.idx = fps_and_knn_xyz(g.xyz, self.npoints[i], self.k, base, g.xyz)
+                else:
+                    fidx, fxyz = farthest_point_sample(g.xyz, self.npoints[i], return_xyz=True)
+            else:
+                if need_xyz:
+                    g.dist, g.idx = knn_point(self.k, base, g.xyz)
+                if feature is not None:
+                    idx_f = knn_point(k_feat, feature, query)[1]
+            if need_fps:
+                n = _GeoLevel()
+                n.xyz, n.fps_idx, n.chain, n.i = fxyz, fidx, self, i + 1
+                self.levels[i + 1] = n
+        return idx_f
 
 
 _GEO_STREAMS = {}

@@ -268,6 +268,21 @@ class _ForcedKnn:
             return (fidx, fxyz) + self.force(dist, idx)
         return f
 
+    def fused2(self, real):
+        """wrapper for ops.fps_knn_fused (next state's sampling + this state's coordinate and feature searches in one
+        launch): both searches are forced, in the reference's order (xyz, then feature).  When the op fell back to
+        the separate (already wrapped) calls, the forcing has happened inside."""
+        def f(fps_in, npoint, k_xyz, xyz_base, xyz_query, k_feat, feat_base, feat_query, start_idx=None):
+            before = self.i
+            fidx, fxyz, rx, rf = real(fps_in, npoint, k_xyz, xyz_base, xyz_query, k_feat, feat_base, feat_query,
+                                      start_idx=start_idx)
+            if self.i == before:
+                if rx is not None:
+                    rx = self.force(*rx)
+                rf = self.force(*rf)
+            return fidx, fxyz, rx, rf
+        return f
+
     def force(self, dist, idx):
         # the reference's recorded call with this shape that has not been used yet (the geometry
         # pass issues all xyz-space kNNs first; per shape the reference's order is xyz, feature)
@@ -286,17 +301,18 @@ def _run_model(g, model, run, patch_mods, prefix):
     patch_mods = list(patch_mods) + [_ops]          # geometry_pass calls ops.knn_point directly
     forced = _ForcedKnn(_ops.knn_point, rec)
     saved = [m.knn_point for m in patch_mods]
-    saved_fused = _ops.fps_and_knn_xyz
+    saved_fused, saved_fused2 = _ops.fps_and_knn_xyz, _ops.fps_knn_fused
     for m in patch_mods:
         m.knn_point = forced
     _ops.fps_and_knn_xyz = forced.fused(saved_fused)
+    _ops.fps_knn_fused = forced.fused2(saved_fused2)
     try:
         torch.manual_seed(2024)
         out = run(model)
     finally:
         for m, s in zip(patch_mods, saved):
             m.knn_point = s
-        _ops.fps_and_knn_xyz = saved_fused
+        _ops.fps_and_knn_xyz, _ops.fps_knn_fused = saved_fused, saved_fused2
     assert forced.i == len(rec)
     return out, forced
 

@@ -487,3 +487,29 @@ def test_max_over_points_matches_torch(ops, B, N, C, dtype):
     first = (xc == want_v).float().argmax(dim=1, keepdim=True)          # first row equal to the maximum
     want_g = torch.zeros(B, N, C).scatter_(1, first, w.float().cpu())
     assert torch.equal(x.grad.float().cpu(), want_g)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,fN,fS,N,S,C,with_xyz", [(4, 512, 256, 1024, 512, 64, True), (40, 1024, 512, 2048, 1024, 64, True),
+                                                     (3, 300, 77, 150, 90, 128, False), (2, 2048, 1000, 333, 333, 64, True),
+                                                     (2, 100, 50, 200, 100, 64, True), (2, 512, 256, 300, 200, 32, True)])
+def test_fused_fps_and_searches_equal_separate_launches(ops, B, fN, fS, N, S, C, with_xyz):
+    """ops.fps_knn_fused (mpa_fps_knn_feat_f32: next state's FPS + this state's coordinate search + its feature
+    search in one launch; the last two rows fall back to the separate launches) == the three entry points."""
+    fin = unit_cloud(B, fN, seed=fN).cuda()
+    xb = unit_cloud(B, N, seed=N + 1).cuda()
+    xq = xb[:, :S].contiguous()
+    fb = randn((B, N, C), seed=C + N).cuda()
+    fq = randn((B, S, C), seed=C + S, scale=0.7).cuda()
+    start = torch.arange(B) % fN
+    fidx, fxyz, rx, (df, jf) = ops.fps_knn_fused(fin, fS, 8, xb if with_xyz else None, xq if with_xyz else None, 8, fb, fq,
+                                                  start_idx=start)
+    fidx0, fxyz0 = ops.farthest_point_sample(fin, fS, start_idx=start, return_xyz=True)
+    assert torch.equal(fidx, fidx0) and torch.equal(fxyz, fxyz0)
+    df0, jf0 = ops.knn_point(8, fb, fq)
+    assert torch.equal(jf, jf0) and torch.equal(df, df0)
+    if with_xyz:
+        dx0, ix0 = ops.knn_point(8, xb.clone(), xq)
+        assert torch.equal(rx[1], ix0) and torch.equal(rx[0], dx0)
+    else:
+        assert rx is None
