@@ -243,7 +243,7 @@ def stacked_param_groups(t1, t2):
             (t1.q.weight, t2.q.weight), (t1.q.bias, t2.q.bias))
 
 
-def local_trans_pair(t1, t2, features, idx1, idx2, center, concat=False):
+def local_trans_pair(t1, t2, features, idx1, idx2, center, concat=False, kvkv=None):
     """t1(features, idx1), t2(features, idx2) for two feature-branch LocalTrans blocks that share
     their base rows and centres (LocalMerge's two feature streams): the four key/value projections
     are one GEMM over the base rows, the two query projections one GEMM over the centres, and the
@@ -252,9 +252,19 @@ def local_trans_pair(t1, t2, features, idx1, idx2, center, concat=False):
         outs = t1(features, idx1, None, center=center), t2(features, idx2, None, center=center)
         return torch.cat(outs, 2) if concat else outs
     qq = ops.linear_stack(center, (t1.q, t2.q), (True, True))
-    kvkv = ops.linear_stack(features, (t1.k, t1.v, t2.k, t2.v), (True, False, True, False))
+    if kvkv is None:        # (LocalMerge hands the projections over when it computed them together with the centres)
+        kvkv = ops.linear_stack(features, (t1.k, t1.v, t2.k, t2.v), (True, False, True, False))
     c1, c2 = ops.diffattn_pair(qq, kvkv, idx1, idx2)
     return finish_group((t1, t2), (c1, c2), (center, center), concat=concat)
+
+
+def centres_and_projections(t1, t2, feature, FPS_idx):
+    """(fs, kvkv): the sampled centres index_points(feature, FPS_idx) and the stacked key | value projections of two
+    feature streams, from one autograd node (ops.gather_and_stack: the features receive one gradient instead of two
+    that autograd has to add).  (fs, None) when that form does not apply."""
+    if FPS_idx is None or t1.usetanh or t2.usetanh:
+        return (feature if FPS_idx is None else index_points(feature, FPS_idx)), None
+    return ops.gather_and_stack(feature, FPS_idx, (t1.k, t1.v, t2.k, t2.v), (True, False, True, False))
 
 
 def _unit_group(units, xs, residuals=None, mode="each"):
@@ -316,31 +326,32 @@ class LocalMerge(nn.Module):
             dist, idx = knn_point(self.knn, base_xyz, xyz) if geometry is None else geometry.xyz_search()
             merge_features = self.xyz_Trans(features=xyz, idx=idx, pos=base_xyz, FPS_idx=FPS_idx, xyz=True)
         else:
-            fs = feature if FPS_idx is None else index_points(feature, FPS_idx)
+            fs, kvkv = centres_and_projections(self.feature_Trans1, self.feature_Trans2, feature, FPS_idx)
             if geometry is None:
                 dist, idx = knn_point(self.knn, base_xyz, xyz)
                 _, idx_feature = knn_point(self.knn, feature, fs)
             else:
                 (dist, idx), idx_feature = geometry.search(self.knn, feature, fs)
-            merge_features = self.fc2(self._three_streams(base_xyz, feature, idx, idx_feature, FPS_idx, fs))
+            merge_features = self.fc2(self._three_streams(base_xyz, feature, idx, idx_feature, FPS_idx, fs, kvkv))
         if FPS_idx is not None:
             normal = index_points(normal, FPS_idx)
         return merge_features, normal, idx, dist
 
-    def _three_streams(self, base_xyz, feature, idx, idx_feature, FPS_idx, fs):
+    def _three_streams(self, base_xyz, feature, idx, idx_feature, FPS_idx, fs, kvkv=None):
         """torch.cat((xyz_Trans(base_xyz, idx), feature_Trans1(feature, idx), feature_Trans2(feature, idx_feature)), 2):
         the attention contexts per stream as before, their closing conv_res / ffn units as groups whose outputs land
         side by side in one tensor."""
         tx, t1, t2 = self.xyz_Trans, self.feature_Trans1, self.feature_Trans2
         if tx.usetanh or t1.usetanh or t2.usetanh:
             xyz_f = tx(features=base_xyz, idx=idx, pos=base_xyz, FPS_idx=FPS_idx, xyz=True)
-            f1, f2 = local_trans_pair(t1, t2, feature, idx, idx_feature, fs)
+            f1, f2 = local_trans_pair(t1, t2, feature, idx, idx_feature, fs, kvkv=kvkv)
             return torch.cat((xyz_f, f1, f2), dim=2)
         cx = index_points(base_xyz, FPS_idx) if FPS_idx is not None else base_xyz
         ctx_x = ops.diffattn_xyz(base_xyz, cx, idx, tx.q.weight, tx.q.bias, tx.k.weight, tx.k.bias, tx.v.weight,
                                  tx.v.bias)
         qq = ops.linear_stack(fs, (t1.q, t2.q), (True, True))
-        kvkv = ops.linear_stack(feature, (t1.k, t1.v, t2.k, t2.v), (True, False, True, False))
+        if kvkv is None:
+            kvkv = ops.linear_stack(feature, (t1.k, t1.v, t2.k, t2.v), (True, False, True, False))
         c1, c2 = ops.diffattn_pair(qq, kvkv, idx, idx_feature)
         return finish_group((tx, t1, t2), (ctx_x, c1, c2), (cx, fs, fs), concat=True)
 

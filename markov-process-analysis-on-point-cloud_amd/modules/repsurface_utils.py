@@ -16,7 +16,7 @@ from .. import ops
 from ..ops import (farthest_point_sample, index_points, knn_point, query_ball_point, query_knn_point,  # noqa: F401
                    sample, square_distance)
 from .pointnet2_utils import (Linear, LocalTrans, UmbrellaSurfaceConstructor, group_by_umbrella,  # noqa: F401
-                               local_trans_pair, resort_points, stacked_param_groups)
+                               centres_and_projections, local_trans_pair, resort_points, stacked_param_groups)
 
 
 def sample_and_group(npoint, radius, nsample, center, normal, feature, return_normal=True, return_polar=False,
@@ -179,14 +179,14 @@ class LocalMerge(nn.Module):
             dist, idx = knn_point(self.knn, base_xyz, xyz) if geometry is None else geometry.xyz_search()
             merge_features = self.xyz_Trans(features=xyz, idx=idx, pos=base_xyz, FPS_idx=FPS_idx, xyz=True)
         else:
-            fs = feature if FPS_idx is None else index_points(feature, FPS_idx)
+            fs, kvkv = centres_and_projections(self.feature_Trans, self.feature_Trans2, feature, FPS_idx)
             if geometry is None:
                 dist, idx = knn_point(self.knn, base_xyz, xyz)
                 _, idx_feature = knn_point(self.knn, feature, fs)
             else:
                 (dist, idx), idx_feature = geometry.search(self.knn, feature, fs)
             merge_features = self.fc2(local_trans_pair(self.feature_Trans, self.feature_Trans2, feature, idx,
-                                                       idx_feature, fs, concat=True))
+                                                       idx_feature, fs, concat=True, kvkv=kvkv))
         return merge_features, normal, idx, dist
 
 

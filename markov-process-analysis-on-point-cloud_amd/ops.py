@@ -1265,6 +1265,74 @@ class _LinearStack(torch.autograd.Function):
         return (gx, None) + tuple(grads)
 
 
+class _GatherStack(torch.autograd.Function):
+    """(index_points(x, idx), x [W_0; W_1; ...]^T + b): the two consumers of a state's features in LocalMerge -- the
+    sampled centres and the stacked key | value projections -- as ONE autograd node, so that x receives ONE gradient:
+    the dX product writes it and the centres' gradient is scattered INTO it (row atomics), instead of a zero fill, a
+    scatter, a dX product and an addition of the two.  fp32 rows only (the scatter adds with float atomics)."""
+
+    @staticmethod
+    def forward(ctx, x, idx, zero_bias, *wb):
+        Ws, bs = wb[0::2], wb[1::2]
+        B, N, K = x.shape
+        S = idx.shape[1]
+        x2 = x.view(B * N, K)
+        Wst, bst = _stacked_all(Ws), _stacked_all(bs)
+        Nt = Wst.shape[0]
+        fs = torch.empty(B, S, K, dtype=x.dtype, device=x.device)
+        _launch("mpa_gather_fwd_f32", _p(x), _p(idx), B, N, S, K, _p(fs), _stream())
+        y = torch.empty(B * N, Nt, dtype=x.dtype, device=x.device)
+        _gemm(x2, K, 0, Wst, K, 1, bst, y, Nt, B * N, Nt, K)
+        ctx.save_for_backward(x2, Wst, idx)
+        ctx.dims = (B, N, S, K)
+        ctx.sizes = [w.shape[0] for w in Ws]
+        ctx.zero_bias = tuple(zero_bias)
+        ctx.direct = [(_direct(w), _direct(b)) for w, b in zip(Ws, bs)]
+        return fs, y.view(B, N, Nt)
+
+    @staticmethod
+    def backward(ctx, g_fs, gy):
+        x2, Wst, idx = ctx.saved_tensors
+        B, N, S, K = ctx.dims
+        M = B * N
+        Nt = Wst.shape[0]
+        dev = x2.device
+        gy, ldg = _rows_ld(gy.reshape(M, Nt))
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty(M, K, dtype=x2.dtype, device=dev)
+            _gemm(gy, ldg, 0, Wst, K, 0, None, gx, K, M, K, Nt)                       # gradient through the projections
+            _launch("mpa_gather_bwd_f32", _p(g_fs.contiguous()), _p(idx), B, N, S, K, _p(gx), _stream())   # += centres
+            gx = gx.view(B, N, K)
+        grads = []
+        off = 0
+        for n_i, zb, (dW, db) in zip(ctx.sizes, ctx.zero_bias, ctx.direct):
+            blk = gy[:, off:off + n_i]
+            gW = dW if dW is not None else torch.empty(n_i, K, dtype=torch.float32, device=dev)
+            if zb:
+                _weight_grad(blk, ldg, x2, K, gW, n_i, K, M, direct=dW is not None)
+                gb = None if db is not None else _zeros_like_cached(dev, n_i)
+            else:
+                gb_buf = db if db is not None else torch.zeros(n_i, dtype=torch.float32, device=dev)
+                _weight_grad(blk, ldg, x2, K, gW, n_i, K, M, a_col_sum=gb_buf, direct=dW is not None and db is not None)
+                gb = None if db is not None else gb_buf
+            grads += [None if dW is not None else gW, gb]
+            off += n_i
+        return (gx, None, None) + tuple(grads)
+
+
+def gather_and_stack(x, idx, layers, zero_bias):
+    """(index_points(x, idx), linear_stack(x, layers, zero_bias)) with one gradient into x (see _GatherStack); storage
+    types other than fp32 take the two separate ops."""
+    _dev(x, idx, layers[0].weight)
+    if x.dtype != torch.float32 or idx.dim() != 2:
+        return index_points(x, idx), linear_stack(x, layers, zero_bias)
+    wb = []
+    for l in layers:
+        wb += [l.weight, l.bias]
+    return _GatherStack.apply(x.contiguous(), _i64(idx), tuple(zero_bias), *wb)
+
+
 def linear_stack(x, layers, zero_bias):
     """[.., sum N_i] = the nn.Linear `layers` applied to x side by side (see _LinearStack)."""
     _dev(x, layers[0].weight)

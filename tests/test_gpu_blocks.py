@@ -964,3 +964,31 @@ def test_linear_unit_group_concat_mode(dtype, tol):
         close(xs_g[i].grad, xs_r[i].grad, "dx%d" % i)
         close(u.linear.weight.grad, r.linear.weight.grad, "dW%d" % i)
         close(u.norm2.weight.grad, r.norm2.weight.grad, "dgamma%d" % i)
+
+
+@pytest.mark.gpu
+def test_gather_and_stack_matches_separate_ops():
+    """ops.gather_and_stack (centres + stacked projections from one autograd node: one gradient into the features)
+    against index_points + linear_stack."""
+    import copy
+    from mpa_amd import ops
+    torch.manual_seed(3)
+    B, N, S, K = 3, 200, 77, 64
+    layers = [torch.nn.Linear(K, n).cuda() for n in (64, 64, 32, 64)]
+    ref_layers = copy.deepcopy(layers)
+    x = torch.randn(B, N, K, device="cuda")
+    idx = torch.stack([torch.randperm(N)[:S] for _ in range(B)]).cuda()
+    xg, xr = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    zb = (True, False, True, False)
+    fs_g, y_g = ops.gather_and_stack(xg, idx, layers, zb)
+    fs_r, y_r = ops.index_points(xr, idx), ops.linear_stack(xr, ref_layers, zb)
+    assert torch.equal(fs_g, fs_r) and torch.equal(y_g, y_r)
+    w1, w2 = torch.randn_like(fs_r), torch.randn_like(y_r)
+    ((fs_g * w1).sum() + (y_g * w2).sum()).backward()
+    ((fs_r * w1).sum() + (y_r * w2).sum()).backward()
+    scale = float(xr.grad.abs().max())
+    assert float((xg.grad - xr.grad).abs().max()) <= 1e-5 * scale
+    for a, b, z in zip(layers, ref_layers, zb):
+        assert torch.allclose(a.weight.grad, b.weight.grad, rtol=1e-5, atol=1e-5 * float(b.weight.grad.abs().max()))
+        if not z:
+            assert torch.allclose(a.bias.grad, b.bias.grad, rtol=1e-5, atol=1e-5 * float(b.bias.grad.abs().max()))
