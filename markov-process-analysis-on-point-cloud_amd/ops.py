@@ -1134,12 +1134,25 @@ class _Linear(torch.autograd.Function):
         return gx, gW, gb, None, None
 
 
+SMALL_ROWS = 128
+
+
+def _small_rows_fp32(x2):
+    """bf16 rows of a per-CLOUD layer (the classification head: M = batch rows) are promoted to fp32: with so few
+    rows the layer is its weight matrix streamed once (fp32 in HBM either way), the fp32 GEMM splits K over the chip
+    where the bf16 kernel's one row tile walks all of K on a handful of workgroups (69 us against 12 for 2048 -> 1024
+    on 64 rows), and everything downstream of it stays fp32 (more accurate, same cost)."""
+    if x2.dtype == torch.bfloat16 and x2.shape[0] <= SMALL_ROWS:
+        return x2.float()
+    return x2
+
+
 def linear(x, weight, bias, bias_grad_is_zero=False, out_dtype=None):
     """y = x W^T + b over the last dimension (nn.Linear), any leading shape.  out_dtype=torch.float32 on
     bf16 features: the product's fp32 results are stored unrounded (logits handed to a loss)."""
     _dev(x, weight)
     lead = x.shape[:-1]
-    y = _Linear.apply(_feat(x).reshape(-1, x.shape[-1]), _f32(weight), bias, bias_grad_is_zero, out_dtype)
+    y = _Linear.apply(_small_rows_fp32(_feat(x).reshape(-1, x.shape[-1])), _f32(weight), bias, bias_grad_is_zero, out_dtype)
     return y.view(*lead, weight.shape[0])
 
 
@@ -1686,7 +1699,7 @@ def linear_bn_act(x, weight, bias, bn, slope, residual=None):
     the same kernel (LocalTrans' `residual + ffn(context)`, Fuse's `conv(x) + f`)."""
     _dev(x, weight)
     lead = x.shape[:-1]
-    x2 = _feat(x).reshape(-1, x.shape[-1])
+    x2 = _small_rows_fp32(_feat(x).reshape(-1, x.shape[-1]))
     training = bn.training or bn.running_mean is None
     if training and x2.shape[0] <= 1:
         raise ValueError("Expected more than 1 value per channel when training (BatchNorm1d)")
