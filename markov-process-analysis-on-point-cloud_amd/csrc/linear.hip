@@ -1485,6 +1485,17 @@ extern "C" int mpa_gemm_tn_grouped_f32(const MpaGemmTnProblem *problems, int cou
     // more problems than one launch's argument block holds: equal-sized launches, in queue order (dealing the
     // fine states' HBM-bound streams out over the launches measured 1-2 % slower: they run best back to back)
     const int launches = mpa_ceil_div(count, GROUP_MAX), chunk = mpa_ceil_div(count, launches);
+    // A queue of a few long, thin products (bf16 features: only the fp32 coordinate units' gradients come here -- rows
+    // of 3 floats, up to 65,536 of them) would stream on a few dozen workgroups at 2048-row chunks (107 us for 17 MB):
+    // when the whole call stays under four workgroups per CU that way, its thin products are cut four times finer.
+    long long est = 0;
+    for (int i = 0; i < count; ++i) {
+        const long long tiles = (long long)mpa_ceil_div(problems[i].M, TS) * mpa_ceil_div(problems[i].N, TS);
+        long long sp = tiles < 128 && problems[i].K >= 4096 ? (256 + tiles - 1) / tiles : 1;
+        if (sp > problems[i].K / 2048) sp = problems[i].K / 2048 > 0 ? problems[i].K / 2048 : 1;
+        est += tiles * sp;
+    }
+    const bool small_launch = est < 1024;
     while (done < count) {
         GroupedArgs ga;
         GroupedReduceArgs ra;
@@ -1502,7 +1513,8 @@ extern "C" int mpa_gemm_tn_grouped_f32(const MpaGemmTnProblem *problems, int cou
             const size_t mn = (size_t)in.M * in.N;
             static const int tn_stream = getenv("MPA_TN_STREAM") ? atoi(getenv("MPA_TN_STREAM")) : 2;
             static const int target_wgs = getenv("MPA_TN_WGS") ? atoi(getenv("MPA_TN_WGS")) : 256;
-            static const int min_kchunk = getenv("MPA_TN_KCHUNK") ? atoi(getenv("MPA_TN_KCHUNK")) : 2048;
+            static const int min_kchunk_env = getenv("MPA_TN_KCHUNK") ? atoi(getenv("MPA_TN_KCHUNK")) : 2048;
+            const int min_kchunk = small_launch ? 512 : min_kchunk_env;
             // tn_stream: 1 = stream every problem, 0 = LDS-staged, 2 = stream the single-/few-tile
             // problems (pure HBM streams) and stage the wide ones (MFMA-bound) through LDS
             q.stream = tn_stream == 2 ? (q.tiles <= 4 ? 1 : 0) : tn_stream;
