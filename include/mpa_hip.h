@@ -396,6 +396,11 @@ int mpa_gather_fwd_bf16(const mpa_bf16 *points, const int64_t *idx, int B, int N
                         mpa_bf16 *out, void *stream);
 int mpa_gather_bwd_bf16(const mpa_bf16 *grad_out, const int64_t *idx, int B, int N, int M, int C,
                         float *grad_points, void *stream);
+/* The same scatter-add INTO a bf16 destination (not cleared: pass zeros for the plain backward of index_points, or a
+ * gradient to add to): two channels per lane, compare-and-swap on the dword.  Exact for rows listed once; rows listed
+ * several times are added one by one, each sum rounded to bf16.  C even, 4-byte aligned rows. */
+int mpa_gather_bwd_into_bf16(const mpa_bf16 *grad_out, const int64_t *idx, int B, int N, int M, int C,
+                             mpa_bf16 *grad_points, void *stream);
 /* difference-wise attention (:548-569) on bf16 q / k / v / ctx (softmax, offset and max in fp32 registers).
  * Backward requires the workspace of mpa_diffattn_bwd_workspace_bytes_bf16() (per-slot key gradients are
  * kept in bf16, summed per base row in fp32, stored bf16; never float atomics on bf16). */

@@ -111,6 +111,7 @@ SIGNATURES.update({
     "mpa_bn_stats_act_fwd_bf16": SIGNATURES["mpa_bn_stats_act_fwd_f32"],
     "mpa_gemm_tn_grouped_bf16": [ctypes.POINTER(GemmTnProblemBf16), _i, _vp, ctypes.c_size_t, _vp],
     "mpa_gemm_grouped_bf16": [ctypes.POINTER(GemmProblem), _i, _i, _i, _vp],
+    "mpa_gather_bwd_into_bf16": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "mpa_bn_act_fwd_bf16": SIGNATURES["mpa_bn_act_fwd_f32"],
     "mpa_bn_act_bwd_reduce_bf16": SIGNATURES["mpa_bn_act_bwd_reduce_f32"],
     "mpa_bn_act_bwd_apply_bf16": SIGNATURES["mpa_bn_act_bwd_apply_f32"],

@@ -43,6 +43,30 @@ __global__ void gather_bwd_kernel(const T *__restrict__ grad_out, const int64_t 
     }
 }
 
+// bf16 rows: grad_points[b, idx[b,m], :] += grad_out[b,m,:] directly on the bf16 destination, two channels (one
+// dword) per lane with a compare-and-swap loop -- exact for rows listed once (the FPS index maps of the models: the
+// result is the bf16 sum the separate zero-fill / fp32 scatter / cast / add produced), race-free for repeated rows
+// (each addition is then rounded to bf16 in turn).
+__global__ void gather_bwd_into_bf16_kernel(const unsigned *__restrict__ grad_out, const int64_t *__restrict__ idx, int N,
+                                            int M, int C2, long long total, unsigned *__restrict__ grad_points)
+{
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long row = i / C2;
+        const int c = (int)(i - row * C2);
+        const int b = (int)(row / M);
+        const long long dst = (long long)b * N + mpa_clamp_idx(idx[row], N);
+        const unsigned g = grad_out[i];
+        unsigned *p = grad_points + dst * C2 + c;
+        unsigned old = *p, assumed;
+        do {
+            assumed = old;
+            const unsigned sum = mpa_pack_bf16x2(mpa_bf16_lo(assumed) + mpa_bf16_lo(g), mpa_bf16_hi(assumed) + mpa_bf16_hi(g));
+            old = atomicCAS(p, assumed, sum);
+        } while (old != assumed);
+    }
+}
+
 // upsample forward, scatter phase: every coarse row s adds itself to the fine rows it lists
 // (once per distinct fine index: scatter_ semantics) and bumps their divisor if p[s][0] != 0.
 __global__ void upsample_scatter_kernel(const float *__restrict__ points, const int64_t *__restrict__ knn, int S,
@@ -332,6 +356,20 @@ extern "C" int mpa_gather_bwd_bf16(const mpa_bf16 *grad_out, const int64_t *idx,
     long long total = (long long)B * M * C;
     hipLaunchKernelGGL(gather_bwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(TPB), 0, (hipStream_t)stream,
                        reinterpret_cast<const bf16_t *>(grad_out), idx, N, M, C, total, grad_points);
+    MPA_LAUNCH_CHECK();
+    return MPA_OK;
+}
+
+extern "C" int mpa_gather_bwd_into_bf16(const mpa_bf16 *grad_out, const int64_t *idx, int B, int N, int M, int C,
+                                        mpa_bf16 *grad_points, void *stream)
+{
+    MPA_CLEAR_ERROR();
+    if (!grad_out || !idx || !grad_points || B <= 0 || N <= 0 || M <= 0 || C <= 0) return MPA_EINVAL;
+    if ((C & 1) != 0 || ((((uintptr_t)grad_out | (uintptr_t)grad_points)) & 3) != 0) return MPA_EUNSUPPORTED;
+    const long long total = (long long)B * M * (C / 2);
+    hipLaunchKernelGGL(gather_bwd_into_bf16_kernel, dim3(grid_for(total)), dim3(TPB), 0, (hipStream_t)stream,
+                       reinterpret_cast<const unsigned *>(grad_out), idx, N, M, C / 2, total,
+                       reinterpret_cast<unsigned *>(grad_points));
     MPA_LAUNCH_CHECK();
     return MPA_OK;
 }

@@ -584,6 +584,12 @@ class _IndexPoints(torch.autograd.Function):
         (flat,) = ctx.saved_tensors
         B, N, M, C = ctx.shape
         grad = grad.contiguous()
+        if grad.dtype == torch.bfloat16 and C % 2 == 0 and M <= N:
+            # index maps of at most N rows (the FPS maps: every row listed once): scattered straight into a bf16
+            # destination (no fp32 staging buffer, no cast)
+            gp = torch.zeros(B, N, C, dtype=torch.bfloat16, device=grad.device)
+            _launch("mpa_gather_bwd_into_bf16", _p(grad), _p(flat), B, N, M, C, _p(gp), _stream())
+            return gp, None
         # rows listed several times are summed in fp32 (float atomics on whole rows), whatever the storage type
         gp = torch.zeros(B, N, C, dtype=torch.float32, device=grad.device)
         _launch("mpa_gather_bwd_" + _sfx(grad), _p(grad), _p(flat), B, N, M, C, _p(gp), _stream())
@@ -1281,8 +1287,8 @@ class _LinearStack(torch.autograd.Function):
 class _GatherStack(torch.autograd.Function):
     """(index_points(x, idx), x [W_0; W_1; ...]^T + b): the two consumers of a state's features in LocalMerge -- the
     sampled centres and the stacked key | value projections -- as ONE autograd node, so that x receives ONE gradient:
-    the dX product writes it and the centres' gradient is scattered INTO it (row atomics), instead of a zero fill, a
-    scatter, a dX product and an addition of the two.  fp32 rows only (the scatter adds with float atomics)."""
+    the dX product writes it and the centres' gradient is scattered INTO it (fp32: row atomics; bf16: compare-and-swap
+    on channel pairs), instead of a zero fill, a scatter, (a cast,) a dX product and an addition of the two."""
 
     @staticmethod
     def forward(ctx, x, idx, zero_bias, *wb):
@@ -1293,7 +1299,7 @@ class _GatherStack(torch.autograd.Function):
         Wst, bst = _stacked_all(Ws), _stacked_all(bs)
         Nt = Wst.shape[0]
         fs = torch.empty(B, S, K, dtype=x.dtype, device=x.device)
-        _launch("mpa_gather_fwd_f32", _p(x), _p(idx), B, N, S, K, _p(fs), _stream())
+        _launch("mpa_gather_fwd_" + _sfx(x), _p(x), _p(idx), B, N, S, K, _p(fs), _stream())
         y = torch.empty(B * N, Nt, dtype=x.dtype, device=x.device)
         _gemm(x2, K, 0, Wst, K, 1, bst, y, Nt, B * N, Nt, K)
         ctx.save_for_backward(x2, Wst, idx)
@@ -1315,7 +1321,8 @@ class _GatherStack(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = torch.empty(M, K, dtype=x2.dtype, device=dev)
             _gemm(gy, ldg, 0, Wst, K, 0, None, gx, K, M, K, Nt)                       # gradient through the projections
-            _launch("mpa_gather_bwd_f32", _p(g_fs.contiguous()), _p(idx), B, N, S, K, _p(gx), _stream())   # += centres
+            _launch("mpa_gather_bwd_f32" if gx.dtype == torch.float32 else "mpa_gather_bwd_into_bf16",
+                    _p(g_fs.contiguous()), _p(idx), B, N, S, K, _p(gx), _stream())                # += centres' gradient
             gx = gx.view(B, N, K)
         grads = []
         off = 0
@@ -1335,15 +1342,14 @@ class _GatherStack(torch.autograd.Function):
 
 
 def gather_and_stack(x, idx, layers, zero_bias):
-    """(index_points(x, idx), linear_stack(x, layers, zero_bias)) with one gradient into x (see _GatherStack); storage
-    types other than fp32 take the two separate ops."""
+    """(index_points(x, idx), linear_stack(x, layers, zero_bias)) with one gradient into x (see _GatherStack)."""
     _dev(x, idx, layers[0].weight)
-    if x.dtype != torch.float32 or idx.dim() != 2:
+    if idx.dim() != 2 or (x.dtype == torch.bfloat16 and x.shape[-1] % 2):
         return index_points(x, idx), linear_stack(x, layers, zero_bias)
     wb = []
     for l in layers:
         wb += [l.weight, l.bias]
-    return _GatherStack.apply(x.contiguous(), _i64(idx), tuple(zero_bias), *wb)
+    return _GatherStack.apply(_feat(x), _i64(idx), tuple(zero_bias), *wb)
 
 
 def linear_stack(x, layers, zero_bias):
