@@ -255,6 +255,7 @@ def main():
     workload += ", %s%s, fwd+loss+bwd+Adam (%s)" % ("fp32" if dt == "f32" else "bf16 features / fp32 accumulate, statistics, "
                                                    "coordinates and parameters", "", which)
 
+    cap = False
     if a.eager:
         reducer = mdist.GradReducer(model) if world > 1 else None
         opt = torch.optim.Adam(model.parameters(), lr=1e-3)
@@ -303,7 +304,7 @@ def main():
     elapsed = mdist.max_over_ranks(elapsed, dev)
     log("rank %d: %d steps in %.3f s" % (rank, a.steps, elapsed))
     assert torch.isfinite(loss).item(), "loss is not finite"
-    if not a.eager and rank == 0:
+    if not a.eager and rank == 0 and not cap:     # (with the all-reduce captured in the pass, rank 0 cannot run it alone)
         # A replayed HIP graph has no per-kernel event hooks: the kernels are timed live, with HIP
         # events on their launch stream, in an eagerly launched pass over the same step right
         # after the timed region (same shapes, same data).
