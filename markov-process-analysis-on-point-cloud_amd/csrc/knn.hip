@@ -509,11 +509,22 @@ __device__ __forceinline__ void knn_mfma_body(const float *__restrict__ base, co
     auto copy_tile = [&](int t) {                // global -> LDS without holding the whole tile
         const float4 *src = reinterpret_cast<const float4 *>(bp + (size_t)t * 32 * CT);
         const int lim = min(32, N - t * 32) * (CP / 4);
-#pragma unroll 4
-        for (int v = 0; v < NV; ++v) {
-            const int i = lane + 64 * v;
-            const int r = i / (CP / 4), c4 = i - r * (CP / 4);
-            *reinterpret_cast<float4 *>(slab + r * PITCH + 4 * c4) = i < lim ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        // 8 loads in flight per lane (4 made a C = 256 tile 8 dependent global round trips: the coarsest states'
+        // searches are one or two workgroups per cloud and see every one of them)
+#pragma unroll
+        for (int v0 = 0; v0 < NV; v0 += 8) {
+            float4 tmp[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = lane + 64 * (v0 + u);
+                tmp[u] = (v0 + u < NV && i < lim) ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = lane + 64 * (v0 + u);
+                const int r = i / (CP / 4), c4 = i - r * (CP / 4);
+                if (v0 + u < NV) *reinterpret_cast<float4 *>(slab + r * PITCH + 4 * c4) = tmp[u];
+            }
         }
     };
     // one tile: stage, norms (A2 model; rows beyond N get +inf so they never qualify), QG interleaved MFMA chains
