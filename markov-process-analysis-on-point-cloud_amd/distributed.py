@@ -237,6 +237,12 @@ class GradReducer:
             for h in self._handles:
                 h.wait()
             self._handles = []
+            # the step's reductions are complete: re-arm every bucket.  zero_grad() also does this, but under HIP-graph
+            # replay zero_grad() runs inside the captured pass only -- Python never executes it again -- so a bucket
+            # left "started" would be skipped by start() AND by this method from the second replayed step on (its
+            # gradients divided by the world size but never summed).
+            for b in self.buckets:
+                b["started"] = False
         if w > 1:
             for b in self.buckets:
                 b["flat"].div_(w)

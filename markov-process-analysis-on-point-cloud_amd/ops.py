@@ -201,8 +201,9 @@ def farthest_point_sample(xyz, npoint, cuda=False, start_idx=None, return_xyz=Fa
     B, N, C = xyz.shape
     start = _fps_start(B, N, xyz.device, start_idx)
     out = torch.empty(B, npoint, dtype=torch.int64, device=xyz.device)
-    if C != 3:
-        # rows of any width (the reference sums the squared differences over all C channels, :103-104)
+    if C != 3 or N > 12288:
+        # rows of any width (the reference sums the squared differences over all C channels, :103-104), and clouds
+        # beyond the register-resident kernel's 12,288 points (the same arithmetic, rows re-read from L2)
         _launch("mpa_fps_generic_f32", _p(xyz), B, N, C, npoint, _p(start), _p(out), _stream())
         return (out, index_points(xyz, out)) if return_xyz else out
     oxyz = torch.empty(B, npoint, 3, dtype=torch.float32, device=xyz.device) if return_xyz else None

@@ -136,3 +136,96 @@ def test_split_reducer_overlaps_and_matches_single_process(tmp_path):
         opt.step()
     for k, v in model.state_dict().items():
         assert torch.allclose(v, dp[k], atol=1e-6), k
+
+
+def _worker_replay(rank, world, port, out):
+    """What GraphedTrainStep.__call__ does after a replayed pass with split_after and capture_reduce=False:
+    start(early) + all_reduce(), step after step, WITHOUT zero_grad() in between (it runs inside the captured
+    graph, not in Python).  Every bucket must be summed over the ranks in every round."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import mpa_amd  # noqa: F401
+    from mpa_amd import distributed as md
+    md.init_process_group("gloo")
+    model = _make_model()
+    red = md.GradReducer(model, bucket_bytes=1 << 20, split_after=model.body[2])
+    red.overlap = False
+    x, y = _data()
+    lo, hi = md.shard_batch(x.shape[0])
+    red.zero_grad()
+    ((model(x[lo:hi]) - y[lo:hi]) ** 2).mean().backward()
+    red.all_reduce()                                   # discovery pass: builds the buckets
+    assert red.early and len(red.buckets) == 2
+    for it in range(4):                                # "replays": the flat buffers are rewritten, no zero_grad()
+        for i, b in enumerate(red.buckets):
+            b["flat"].fill_(float((rank + 1) * (it + 1) * (i + 1)))
+        red.start(red.early)
+        red.all_reduce()
+        for i, b in enumerate(red.buckets):
+            want = sum((r + 1) * (it + 1) * (i + 1) for r in range(world)) / world
+            assert torch.allclose(b["flat"], torch.full_like(b["flat"], want)), (it, i, float(b["flat"][0]), want)
+    if rank == 0:
+        open(out, "w").write("ok")
+    md.barrier()
+    md.shutdown()
+
+
+def test_split_reducer_rearms_without_zero_grad(tmp_path):
+    world, port, out = 2, _free_port(), str(tmp_path / "replay.txt")
+    mp.spawn(_worker_replay, args=(world, port, out), nprocs=world, join=True)
+    assert open(out).read() == "ok"
+
+
+class _PairNet(torch.nn.Module):
+    """two projections a module wants back to back in the flat buffers (as LocalTrans' k | v)"""
+
+    def __init__(self):
+        super().__init__()
+        self.k = torch.nn.Linear(8, 6)
+        self.mid = torch.nn.Linear(8, 8)
+        self.v = torch.nn.Linear(8, 6)
+
+    def mpa_adjacent_params(self):
+        return ((self.k.weight, self.v.weight), (self.k.bias, self.v.bias))
+
+    def forward(self, x):
+        h = self.mid(x)
+        return (self.k(h) * self.v(h)).sum(-1)
+
+
+def _worker_direct(rank, world, port, out):
+    """GradReducer(direct=True) on a module with mpa_adjacent_params: the grouped parameters' flat views are
+    adjacent, `_mpa_grad_buf` is installed (what the libmpa backward kernels write through), writes through it
+    land in .grad, and the reduced result equals one process."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import mpa_amd  # noqa: F401
+    from mpa_amd import distributed as md
+    md.init_process_group("gloo")
+    torch.manual_seed(0)
+    model = _PairNet()
+    red = md.GradReducer(model, bucket_bytes=1 << 20, direct=True)
+    red.overlap = False
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(10, 8, generator=g)
+    lo, hi = md.shard_batch(10)
+    red.zero_grad()
+    model(x[lo:hi]).sum().backward()
+    red.all_reduce()
+    kw, vw = model.k.weight.grad, model.v.weight.grad
+    assert vw.data_ptr() == kw.data_ptr() + 4 * ((kw.numel() + 3) // 4 * 4)          # back to back (16-byte aligned)
+    assert all(getattr(p, "_mpa_grad_buf", None) is p.grad for p in model.parameters())
+    red.zero_grad()
+    for p in model.parameters():                       # a "kernel" writing straight into the flat gradients
+        p._mpa_grad_buf.fill_(float(rank + 1))
+    red.all_reduce()
+    for p in model.parameters():
+        assert torch.allclose(p.grad, torch.full_like(p.grad, (1 + world) / 2))
+    if rank == 0:
+        open(out, "w").write("ok")
+    md.barrier()
+    md.shutdown()
+
+
+def test_direct_reducer_with_adjacent_params(tmp_path):
+    world, port, out = 2, _free_port(), str(tmp_path / "direct.txt")
+    mp.spawn(_worker_direct, args=(world, port, out), nprocs=world, join=True)
+    assert open(out).read() == "ok"

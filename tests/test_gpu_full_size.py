@@ -202,3 +202,134 @@ def test_completion_chain_16384_bf16(ops):
     ops.upsample(p16, idx).backward(w)
     ops.upsample(p32, idx).backward(w.float())
     assert torch.equal(p16.grad, p32.grad.to(torch.bfloat16))
+
+
+# ------------------------------------------------------------------- configs[3] / configs[4] as full-batch workloads
+def _captured_steps(model, crit, batch, compute_loss, steps):
+    from mpa_amd.runtime import GraphedTrainStep
+    step = GraphedTrainStep(model, crit, batch, lr=1e-3, compute_loss=compute_loss)
+    try:
+        losses = [float(step(*batch).detach()) for _ in range(steps)]
+        torch.cuda.synchronize()
+    finally:
+        step.close()
+    return losses
+
+
+def test_s3dis_full_batch_step(ops, monkeypatch):
+    """BASELINE configs[3] at its per-GPU size -- the part-seg encoder-decoder wiring on 4096-point blocks (states 4096
+    -> 2048 -> 1024 -> 512 -> 256), 13 classes, batch 16, fp32 -- through the captured training step: finite and
+    falling loss, every live parameter receives a finite gradient; in eval mode with fixed sampling starts a block's
+    logits do not depend on the rest of its batch.  (No reference model exists for this configuration: the blocks are
+    pinned one by one in test_gpu_blocks.py, the wiring by the 2048-point golden model; "parity unpinned beyond op
+    level", SURVEY 8d item 4.)"""
+    from mpa_amd.models.repsurf.pointnet2_part_seg_msg import get_model, get_loss
+    B, N, NC = 16, 4096, 13
+    g = torch.Generator().manual_seed(5)
+    x = unit_cloud(B, N, seed=21).transpose(1, 2).contiguous().cuda()
+    label = torch.zeros(B, 1, 16)
+    label[:, 0, 0] = 1
+    label = label.cuda()
+    target = torch.randint(0, NC, (B, N), generator=g).cuda()
+    torch.manual_seed(0)
+    model = get_model(NC).cuda().train()
+
+    def compute_loss(model, crit, x, label, target):
+        pred, _ = model(x, label)
+        assert pred.shape == (B, N, NC) and pred.dtype == torch.float32
+        return crit(pred.reshape(-1, NC), target.reshape(-1))
+
+    losses = _captured_steps(model, get_loss(), (x, label, target), compute_loss, 8)
+    live = [p for p in model.parameters() if p.grad is not None]
+    assert len(live) > 400 and all(torch.isfinite(p.grad).all() for p in live)
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    monkeypatch.setattr(ops, "_fps_start", lambda B, N, device, start_idx=None: torch.zeros(B, dtype=torch.int64, device=device))
+    model.eval()
+    with torch.no_grad():
+        full, _ = model(x, label)
+        one, _ = model(x[5:6].contiguous(), label[5:6].contiguous())
+    assert torch.allclose(full[5:6], one, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_completion_full_batch_step(ops, dtype):
+    """BASELINE configs[4] at its per-GPU size -- the completion chain `upsample` + `LocalMerge`, 1024 -> 2048 -> 4096 ->
+    8192 -> 16,384 points, batch 8 (131,072 rows in the last state: beyond the inverted-table and grouped-launch
+    limits of the smaller configurations) -- through the captured training step, on fp32 and on bf16 features: finite
+    and falling loss, every live parameter receives a finite fp32 gradient; in eval mode a cloud's prediction does
+    not depend on the rest of its batch."""
+    from mpa_amd.models.completion import CompletionDecoder, CoordinateLoss, sampling_order
+    B, N = 8, 16384
+    x = sampling_order(unit_cloud(B, N, seed=31).cuda(), start_idx=torch.zeros(B, dtype=torch.long))
+    x = x.transpose(1, 2).contiguous()
+    torch.manual_seed(0)
+    model = CompletionDecoder().cuda().train()
+
+    def compute_loss(model, crit, x):
+        pred = model(x)
+        assert pred.shape == (B, N, 3) and pred.dtype == torch.float32
+        return crit(pred, x)
+
+    with ops.feature_dtype(dtype):
+        losses = _captured_steps(model, CoordinateLoss(), (x,), compute_loss, 8)
+        live = [p for p in model.parameters() if p.grad is not None]
+        assert len(live) > 100 and all(p.grad.dtype == torch.float32 and torch.isfinite(p.grad).all() for p in live)
+        assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+        model.eval()
+        with torch.no_grad():
+            full = model(x)
+            one = model(x[3:4].contiguous())
+        tol = dict(rtol=1e-4, atol=1e-5) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+        assert torch.allclose(full[3:4], one, **tol)
+
+
+def test_sampling_order_prefixes_are_fps_states(ops, co):
+    """models/completion.py's geometry contract: after sampling_order() the S-point prefix of a cloud is the reference's
+    FPS sample of S points (same first point), for every S -- checked against the C oracle on a 16,384-point cloud
+    (the generic FPS kernel: beyond the register-resident kernel's 12,288 points)."""
+    from mpa_amd.models.completion import sampling_order
+    B, N = 2, 16384
+    xyz = unit_cloud(B, N, seed=41)
+    start = torch.tensor([5, 16000])
+    got = sampling_order(xyz.cuda(), start_idx=start).cpu().numpy()
+    want_idx = co.farthest_point_sample(xyz.numpy(), 4096, start.numpy())
+    assert np.array_equal(got[:, :4096], np.take_along_axis(xyz.numpy(), want_idx[..., None], axis=1))
+    idx_full = ops.farthest_point_sample(xyz.cuda(), N, start_idx=start).cpu().numpy()
+    assert all(len(set(idx_full[b].tolist())) == N for b in range(B))          # a permutation: every point once
+
+
+@pytest.mark.parametrize("N", [8192, 16384])
+def test_completion_localmerge_vs_oracle(ops, N):
+    """The completion chain's transition block at its two largest states -- LocalMerge(64, 64, 8) of an N-point state
+    in itself (coordinate search, feature-space search, three attention streams, fc2; reference
+    modules/pointnet2_utils.py:427-477) -- on one cloud against oracle/ref_cpu.py: neighbour indices bit-exact,
+    features <= 1e-4 in fp32, gradient w.r.t. the input features <= 1e-4 x its scale; on bf16 features against the
+    same fp32 oracle at the bf16 storage tolerance (relative L2 <= 2e-2)."""
+    from mpa_amd.modules import pointnet2_utils as P2
+    from oracle import ref_cpu as R
+    from param_fill import fill_state
+    xyz = unit_cloud(1, N, seed=N)
+    feat = randn((1, N, 64), seed=N + 1)
+    w = randn((1, N, 64), seed=N + 2)
+    cpu = fill_state(R.LocalMergeSeg(64, 64, 8, residual=False), seed=3).train()
+    fc = feat.clone().requires_grad_(True)
+    oc, _, oidx, _ = cpu(xyz=xyz, base_xyz=xyz, normal=None, feature=fc)
+    (oc * w).sum().backward()
+    gpu = fill_state(P2.LocalMerge(64, 64, 8, residual=False), seed=3).cuda().train()
+    fg = feat.cuda().requires_grad_(True)
+    og, _, gidx, _ = gpu(xyz=xyz.cuda(), base_xyz=xyz.cuda(), normal=None, feature=fg)
+    assert torch.equal(gidx.cpu(), oidx)
+    assert (og.detach().cpu() - oc.detach()).abs().max().item() < 1e-4
+    (og * w.cuda()).sum().backward()
+    assert (fg.grad.cpu() - fc.grad).abs().max().item() < 1e-4 * max(1.0, fc.grad.abs().max().item())
+    # bf16 features: same block, inputs rounded to bf16, against the fp32 oracle on the rounded inputs' neighbourhoods
+    with ops.feature_dtype(torch.bfloat16):
+        gpu16 = fill_state(P2.LocalMerge(64, 64, 8, residual=False), seed=3).cuda().train()
+        f16 = feat.to(torch.bfloat16).cuda().requires_grad_(True)
+        o16 = gpu16(xyz=xyz.cuda(), base_xyz=xyz.cuda(), normal=None, feature=f16)[0]
+        assert o16.dtype == torch.bfloat16
+        rel = ((o16.detach().float().cpu() - oc.detach()).norm() / oc.detach().norm()).item()
+        assert rel < 2e-2, rel
+        (o16.float() * w.cuda()).sum().backward()
+        grel = ((f16.grad.float().cpu() - fc.grad).norm() / fc.grad.norm()).item()
+        assert grel < 5e-2, grel
