@@ -10,18 +10,27 @@ the timed region; weak scaling (per-GPU batch fixed).
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
---config   cls-fp32      ModelNet40-shaped classification, 1024 points, batch 64/GPU, fp32   (BASELINE configs[1]; default,
-                         the configuration BASELINE.json's metric is quoted on)
-           cls-bf16      the same model on bf16 features
-           partseg-fp32  ShapeNetPart-shaped part segmentation, 2048 points, batch 32/GPU, fp32
-           partseg-bf16  the same on bf16 features                                            (BASELINE configs[2])
+--config   cls-fp32         ModelNet40-shaped classification, 1024 points, batch 64/GPU, fp32   (BASELINE configs[1]; default,
+                            the configuration BASELINE.json's metric is quoted on)
+           cls-bf16         the same model on bf16 features
+           partseg-fp32     ShapeNetPart-shaped part segmentation, 2048 points, batch 32/GPU, fp32
+           partseg-bf16     the same on bf16 features                                            (BASELINE configs[2])
+           s3dis-fp32       S3DIS-shaped semantic segmentation: the part-seg encoder-decoder wiring on 4096-point
+                            blocks (4096 -> 2048 -> 1024 -> 512 -> 256), 13 classes, batch 16/GPU, fp32  (configs[3])
+           completion-bf16  completion decoder: upsample + LocalMerge, 1024 -> ... -> 16,384 output points,
+                            batch 8/GPU, bf16 features                                           (configs[4])
+           completion-fp32  the same at fp32
 
 Rank 0 prints ONE JSON line.  Extra objects: "roofline" for the dominant kernel (HIP events on the launch
 stream around that kernel's launches), "cpu_baseline" (the CPU oracle oracle/ref_cpu.py timed on this box's
-host cores on a bounded sample; rank 0, N=1, cls configs) and, at N=1, "forward_only" (the forward pass alone
-as a HIP graph, measured after the timed region: a secondary figure).
+host cores on a bounded sample; rank 0, N=1, cls configs), at N=1 "forward_only" (the forward pass alone
+as a HIP graph, measured after the timed region: a secondary figure) and -- in the default run (N=1, default
+config) -- "soak" (400 more replayed steps of the headline workload, same process, same graph) and
+"other_configs": the other BASELINE configurations timed in the same process after the headline, each with
+its own throughput, ms/step and dominant-kernel roofline (--no-others skips them).
 """
 import argparse
+import gc
 import glob
 import hashlib
 import json
@@ -44,7 +53,11 @@ CONFIGS = {
     "cls-bf16": ("cls", "bf16", 1024, 64, "configs[1]'s model on bf16 features"),
     "partseg-fp32": ("partseg", "f32", 2048, 32, "configs[2]'s model at fp32"),
     "partseg-bf16": ("partseg", "bf16", 2048, 32, "BASELINE configs[2]"),
+    "s3dis-fp32": ("s3dis", "f32", 4096, 16, "BASELINE configs[3]"),
+    "completion-bf16": ("completion", "bf16", 16384, 8, "BASELINE configs[4]"),
+    "completion-fp32": ("completion", "f32", 16384, 8, "configs[4]'s chain at fp32"),
 }
+OTHER_CONFIGS = ("partseg-bf16", "s3dis-fp32", "completion-bf16", "cls-bf16", "partseg-fp32")   # after the headline, N=1
 # kernels timed with HIP events for the roofline leg: name -> bound.  fp32: the 64x64-tile GEMM is priced
 # against the fp32 MFMA peak, the short-K kernel (K <= 128 layers, 16 FLOP/B) against HBM.  bf16: every
 # product of the path is below the machine balance (32..200 FLOP/B against ~310), so all are priced on HBM.
@@ -55,7 +68,7 @@ TIMED = {
              "mpa_knn_f32": "mfma",
              "mpa_diffattn_fwd_bf16": "hbm", "mpa_diffattn_bwd_bf16": "hbm"},
 }
-NUM_CLASS, NUM_PART, NUM_OBJ = 40, 50, 16
+NUM_CLASS, NUM_PART, NUM_OBJ, NUM_SEM = 40, 50, 16, 13
 
 
 def unit_clouds(B, N, g):
@@ -70,9 +83,17 @@ def synthetic_batch(task, B, N, seed, device):
     x = unit_clouds(B, N, g)
     if task == "cls":
         return (x.to(device), torch.randint(0, NUM_CLASS, (B,), generator=g).to(device))
+    if task == "completion":
+        # dense clouds in sampling order (every prefix = the FPS state of that size): the data-preparation step of
+        # models/completion.py, done once here like the offline FPS of dataset/ModelNetDataLoader.py
+        if str(device) == "cpu":
+            return (x,)
+        from mpa_amd.models.completion import sampling_order
+        start = torch.randint(0, N, (B,), generator=g)
+        return (sampling_order(x.transpose(1, 2).contiguous().to(device), start_idx=start).transpose(1, 2).contiguous(),)
     label = torch.zeros(B, 1, NUM_OBJ)
     label[torch.arange(B), 0, torch.randint(0, NUM_OBJ, (B,), generator=g)] = 1
-    target = torch.randint(0, NUM_PART, (B, N), generator=g)
+    target = torch.randint(0, NUM_SEM if task == "s3dis" else NUM_PART, (B, N), generator=g)
     return (x.to(device), label.to(device), target.to(device))
 
 
@@ -150,12 +171,12 @@ def forward_only(run_forward, feeder, arena, batch, iters=50):
     return {"value": batch / dt, "unit": "point-clouds/s", "ms_per_step": dt * 1e3, "steps": iters}
 
 
-def cpu_baseline(task, batch, npoint, steps=3):
+def cpu_baseline(task, batch, npoint, warm=1, steps=3):
     """The oracle's plain-PyTorch restatement of the reference path, fwd+bwd+Adam on host cores (fp32: the
     reference has no reduced-precision mode)."""
     from oracle import ref_cpu as R
     threads = int(os.environ.get("MPA_CPU_THREADS", host_cores()))
-    log("cpu baseline on %d threads (os.cpu_count()=%s)" % (threads, os.cpu_count()))
+    log("cpu baseline (%s, batch %d) on %d threads (os.cpu_count()=%s)" % (task, batch, threads, os.cpu_count()))
     torch.set_num_threads(threads)
     torch.manual_seed(0)
     if task == "cls":
@@ -166,14 +187,15 @@ def cpu_baseline(task, batch, npoint, steps=3):
         loss_of = lambda out: R.smooth_cls_loss(out, y)          # noqa: E731
         name = "ClsModel"
     else:
-        model = R.PartSegModel(NUM_PART).train()
+        nc = NUM_SEM if task == "s3dis" else NUM_PART
+        model = R.PartSegModel(nc).train()
         x, lab, tgt = synthetic_batch(task, batch, npoint, 1234, "cpu")
         fwd = lambda: model(x, lab)[0]                           # noqa: E731
-        loss_of = lambda out: R.partseg_loss(out.reshape(-1, NUM_PART), tgt.reshape(-1))        # noqa: E731
+        loss_of = lambda out: R.partseg_loss(out.reshape(-1, nc), tgt.reshape(-1))        # noqa: E731
         name = "PartSegModel"
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
     times = []
-    for i in range(steps + 1):
+    for i in range(warm + steps):
         t0 = time.perf_counter()
         opt.zero_grad(set_to_none=True)
         loss = loss_of(fwd())
@@ -181,82 +203,92 @@ def cpu_baseline(task, batch, npoint, steps=3):
         opt.step()
         times.append(time.perf_counter() - t0)
         log("cpu baseline step %d: %.2f s" % (i, times[-1]))
-    times = sorted(times[1:])
+    times = sorted(times[warm:])
     med = times[len(times) // 2]
     ftimes = []
     with torch.no_grad():                                  # forward only (the >= 20x target is on forward)
-        for i in range(steps + 1):
+        for i in range(1 + max(2, steps // 2)):
             t0 = time.perf_counter()
             fwd()
             ftimes.append(time.perf_counter() - t0)
     fmed = sorted(ftimes[1:])[len(ftimes[1:]) // 2]
     log("cpu baseline forward only: %.2f s" % fmed)
     return {"value": batch / med, "unit": "point-clouds/s", "cores": threads, "kind": "port",
-            "sample": "oracle/ref_cpu.py %s fp32 fwd+bwd+Adam, batch %d x %d pts, 1 warm-up + %d timed steps, median"
-                      % (name, batch, npoint, steps),
+            "sample": "oracle/ref_cpu.py %s fp32 fwd+bwd+Adam, batch %d x %d pts, %d warm-up + %d timed steps, median"
+                      % (name, batch, npoint, warm, steps),
             "forward_only_value": batch / fmed}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", choices=sorted(CONFIGS), default="cls-fp32")
-    ap.add_argument("--batch", type=int, default=0, help="clouds per GPU (default: the configuration's)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-forward-only", action="store_true", help="skip the secondary forward-only leg (profiling runs)")
-    ap.add_argument("--eager", action="store_true", help="launch every kernel from Python (no HIP graph)")
-    a = ap.parse_args()
-    task, dt, npoint, dbatch, which = CONFIGS[a.config]
-    batch = a.batch or dbatch
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
-    local = local % torch.cuda.device_count()      # (rehearsals may stack ranks on one card)
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-
-    import mpa_amd  # noqa: F401
-    from mpa_amd import ops
-    from mpa_amd import distributed as mdist
-
-    if world > 1:
-        mdist.init_process_group(os.environ.get("MPA_DIST_BACKEND"))
-    ops.set_feature_dtype(torch.bfloat16 if dt == "bf16" else torch.float32)
+def build_workload(name, batch, rank, dev):
+    """model, loss, resident synthetic batch and the callables of one configuration."""
+    task, dt, npoint, dbatch, which = CONFIGS[name]
     torch.manual_seed(0)
     data = synthetic_batch(task, batch, npoint, 1234 + rank, dev)
+    w = {"task": task, "dt": dt, "npoint": npoint, "batch": batch, "data": data, "compute_loss": None, "split": None}
     if task == "cls":
         from mpa_amd.models.repsurf.repsurf_ssg_umb import Model, SmoothClsLoss
         args = argparse.Namespace(num_point=npoint, return_dist=True, cuda_ops=True, num_class=NUM_CLASS)
         model = Model(args).to(dev).train()
         crit = SmoothClsLoss()
-        compute_loss = None
-        run_forward = lambda: model(data[0])                     # noqa: E731
-        loss_eager = lambda: crit(model(data[0]), data[1])       # noqa: E731
-        metric = "point-clouds/sec fwd+bwd, ModelNet40 1024pt cls"
+        w["run_forward"] = lambda: model(data[0])
+        w["loss_eager"] = lambda: crit(model(data[0]), data[1])
+        w["split"] = model.keepHigh.la4
+        w["metric"] = "point-clouds/sec fwd+bwd, ModelNet40 1024pt cls"
         workload = "ModelNet40-shaped classification, %d points, batch %d per GPU" % (npoint, batch)
+    elif task == "completion":
+        from mpa_amd.models.completion import CompletionDecoder, CoordinateLoss
+        model = CompletionDecoder().to(dev).train()
+        crit = CoordinateLoss()
+
+        def compute_loss(model, crit, x):
+            return crit(model(x), x)
+
+        w["compute_loss"] = compute_loss
+        w["run_forward"] = lambda: model(data[0])
+        w["loss_eager"] = lambda: compute_loss(model, crit, *data)
+        w["metric"] = "point-clouds/sec fwd+bwd, completion decoder to 16384 points"
+        workload = ("completion decoder (upsample + LocalMerge chain 1024 -> 2048 -> 4096 -> 8192 -> %d output points, "
+                    "clouds resident in sampling order), batch %d per GPU" % (npoint, batch))
     else:
         from mpa_amd.models.repsurf.pointnet2_part_seg_msg import get_model, get_loss
-        model = get_model(NUM_PART).to(dev).train()
+        nc = NUM_SEM if task == "s3dis" else NUM_PART
+        model = get_model(nc).to(dev).train()
         crit = get_loss()
 
         def compute_loss(model, crit, x, label, target):
             pred, _ = model(x, label)
-            return crit(pred.reshape(-1, NUM_PART), target.reshape(-1))
+            return crit(pred.reshape(-1, nc), target.reshape(-1))
 
-        run_forward = lambda: model(data[0], data[1])            # noqa: E731
-        loss_eager = lambda: compute_loss(model, crit, *data)    # noqa: E731
-        metric = "point-clouds/sec fwd+bwd, ShapeNetPart 2048pt part-seg"
-        workload = "ShapeNetPart-shaped part segmentation, %d points, batch %d per GPU" % (npoint, batch)
-    workload += ", %s%s, fwd+loss+bwd+Adam (%s)" % ("fp32" if dt == "f32" else "bf16 features / fp32 accumulate, statistics, "
-                                                   "coordinates and parameters", "", which)
+        w["compute_loss"] = compute_loss
+        w["run_forward"] = lambda: model(data[0], data[1])
+        w["loss_eager"] = lambda: compute_loss(model, crit, *data)
+        if task == "s3dis":
+            w["metric"] = "point-clouds/sec fwd+bwd, S3DIS-shaped 4096pt blocks sem-seg"
+            workload = ("S3DIS-shaped semantic segmentation (part-seg encoder-decoder wiring, states 4096 -> 2048 -> 1024 -> "
+                        "512 -> 256, %d classes), %d-point blocks, batch %d per GPU" % (nc, npoint, batch))
+        else:
+            w["metric"] = "point-clouds/sec fwd+bwd, ShapeNetPart 2048pt part-seg"
+            workload = "ShapeNetPart-shaped part segmentation, %d points, batch %d per GPU" % (npoint, batch)
+    w["model"], w["crit"] = model, crit
+    w["workload"] = workload + ", %s, fwd+loss+bwd+Adam (%s)" % (
+        "fp32" if dt == "f32" else "bf16 features / fp32 accumulate, statistics, coordinates and parameters", which)
+    return w
 
+
+def run_config(name, a, world, rank, dev, steps, warmup, headline):
+    """Time `steps` steps of one configuration (after `warmup` untimed ones) and price its kernels.  headline: the
+    line the driver reads (barriers, max over ranks, forward-only / soak / CPU legs); otherwise a compact record
+    for "other_configs" (N=1 only)."""
+    from mpa_amd import ops
+    from mpa_amd import distributed as mdist
+    task, dt, npoint, dbatch, which = CONFIGS[name]
+    batch = (a.batch or dbatch) if headline else dbatch
+    old_dtype = ops.set_feature_dtype(torch.bfloat16 if dt == "bf16" else torch.float32)
+    w = build_workload(name, batch, rank, dev)
+    model, crit, data = w["model"], w["crit"], w["data"]
+    graphed = None
     cap = False
-    if a.eager:
+    if a.eager and headline:
         reducer = mdist.GradReducer(model) if world > 1 else None
         opt = torch.optim.Adam(model.parameters(), lr=1e-3)
 
@@ -265,7 +297,7 @@ def main():
                 reducer.zero_grad()
             else:
                 opt.zero_grad(set_to_none=True)
-            loss = loss_eager()
+            loss = w["loss_eager"]()
             loss.backward()
             if reducer is not None:
                 reducer.all_reduce()
@@ -276,46 +308,63 @@ def main():
         from mpa_amd.runtime import GraphedTrainStep
         # MPA_CAPTURE_REDUCE=1 (N > 1): flush the weight gradients of head / la5 / la4 (96 % of the bytes) early and
         # all-reduce them INSIDE the captured graph, overlapped with the rest of backward.  Off by default: RCCL under
-        # graph capture could not be exercised on the one-GPU boxes this was developed on.
-        cap = world > 1 and os.environ.get("MPA_CAPTURE_REDUCE") == "1"
-        split = (model.keepHigh.la4 if cap else None)
-        graphed = GraphedTrainStep(model, crit, data, lr=1e-3, compute_loss=compute_loss, split_after=split,
-                                   capture_reduce=cap)                # optim.FlatAdam on the flat buckets
+        # graph capture has run on one rank only (tests/test_gpu_rccl_capture.py), never across GPUs.
+        cap = world > 1 and os.environ.get("MPA_CAPTURE_REDUCE") == "1" and w["split"] is not None
+        graphed = GraphedTrainStep(model, crit, data, lr=1e-3, compute_loss=w["compute_loss"],
+                                   split_after=w["split"] if cap else None, capture_reduce=cap)   # optim.FlatAdam
 
         def step():
             return graphed(*data)
 
-    for _ in range(a.warmup):
+    eager = a.eager and headline
+    for _ in range(warmup):
         step()
     torch.cuda.synchronize()
-    log("rank %d: warm-up done" % rank)
+    log("rank %d: %s warm-up done" % (rank, name))
     timed = dict(TIMED[dt])
     timed.update({"mpa_fps_knn_xyz_f32": None, "mpa_fps_f32": None})      # the sampling chain: reported as `fps`, not priced
-    if a.eager:
+    if eager:
         ops.enable_kernel_timing(list(timed))
-    mdist.barrier()
+    if headline:
+        mdist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for _ in range(steps):
         loss = step()
     torch.cuda.synchronize()
-    mdist.barrier()
+    if headline:
+        mdist.barrier()
     elapsed = time.perf_counter() - t0
-    elapsed = mdist.max_over_ranks(elapsed, dev)
-    log("rank %d: %d steps in %.3f s" % (rank, a.steps, elapsed))
+    if headline:
+        elapsed = mdist.max_over_ranks(elapsed, dev)
+    log("rank %d: %s: %d steps in %.3f s" % (rank, name, steps, elapsed))
     assert torch.isfinite(loss).item(), "loss is not finite"
-    if not a.eager and rank == 0 and not cap:     # (with the all-reduce captured in the pass, rank 0 cannot run it alone)
+    soak = None
+    if headline and world == 1 and not eager and a.soak > 0:
+        # a longer run of the same replayed step in the same process (the timed region above is ~0.1 s)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(a.soak):
+            loss = step()
+        torch.cuda.synchronize()
+        dts = time.perf_counter() - t1
+        assert torch.isfinite(loss).item(), "loss is not finite after the soak"
+        soak = {"steps": a.soak, "ms_per_step": dts / a.soak * 1e3, "value": batch * a.soak / dts, "unit": "point-clouds/s"}
+        log("soak: %d steps, %.3f ms/step" % (a.soak, soak["ms_per_step"]))
+    n_timed_passes = steps if eager else min(steps, 10 if headline else 3)
+    if not eager and rank == 0 and not cap:     # (with the all-reduce captured in the pass, rank 0 cannot run it alone)
         # A replayed HIP graph has no per-kernel event hooks: the kernels are timed live, with HIP
         # events on their launch stream, in an eagerly launched pass over the same step right
         # after the timed region (same shapes, same data).
         ops.enable_kernel_timing(list(timed))
         fused = ops.set_fps_feature_fusion(False)     # one entry point per event bracket: FPS and the searches apart
-        for _ in range(min(a.steps, 10)):
+        for _ in range(n_timed_passes):
             graphed._fwd_bwd()
         ops.set_fps_feature_fusion(fused)
     kt = ops.kernel_timing_results()
     ops.disable_kernel_timing()
     pair_us = None
+    line = None
     if rank == 0:       # what an (empty) HIP event pair itself costs on this stream: the bracket's overhead
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(100)]
         for e0, e1 in evs:
@@ -325,13 +374,13 @@ def main():
         pair_us = sorted(e0.elapsed_time(e1) * 1e3 for e0, e1 in evs)[50]
 
     if rank == 0:
-        clouds = batch * world * a.steps
+        clouds = batch * world * steps
         # HBM bytes per launch come from committed rocprofv3 PMC passes (collected offline exactly as
         # MI355X_MICROARCH.md prescribes: separate --pmc FETCH_SIZE / WRITE_SIZE runs).  The file records the
         # sha of the kernel sources it measured; if the sources have changed since, traffic is reported as null.
         traffic, traffic_source = {}, None
         src_sha = kernel_sources_sha()
-        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_pmc_traffic.json" % a.config.replace("-", "_"))))
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_pmc_traffic.json" % name.replace("-", "_"))))
         if cands:
             try:
                 with open(cands[-1]) as fh:
@@ -345,20 +394,19 @@ def main():
             except (OSError, ValueError, KeyError):
                 pass
         peak_mfma = MFMA_F32_PEAK_TFLOPS if dt == "f32" else MFMA_BF16_PEAK_TFLOPS
-        n_timed_passes = a.steps if a.eager else min(a.steps, 10)
         kernels = []
-        for name, bound in timed.items():
-            r = kt.get(name)
+        for kname, bound in timed.items():
+            r = kt.get(kname)
             if bound is None or not r or not r["launches"]:
                 continue
             sec = r["ms"] / 1e3
             if bound == "hbm":
                 ach, peak, unit = r["algo_bytes"] / sec / 1e9, HBM_PEAK_GBS, "GB/s"
             else:
-                pk = MFMA_F32_PEAK_TFLOPS if name.endswith("_f32") or "_f32/" in name else peak_mfma
+                pk = MFMA_F32_PEAK_TFLOPS if kname.endswith("_f32") or "_f32/" in kname else peak_mfma
                 ach, peak, unit = r["algo_flops"] / sec / 1e12, pk, "TFLOP/s"
-            kernels.append({"kernel": name, "bound": bound, "achieved": ach, "peak": peak, "unit": unit,
-                            "frac": ach / peak, "traffic": traffic.get(name), "launches": r["launches"],
+            kernels.append({"kernel": kname, "bound": bound, "achieved": ach, "peak": peak, "unit": unit,
+                            "frac": ach / peak, "traffic": traffic.get(kname), "launches": r["launches"],
                             "avg_launch_us": r["ms"] * 1e3 / r["launches"], "total_ms": r["ms"],
                             "algo_bytes_per_launch": r["algo_bytes"] / r["launches"],
                             "algo_flops_per_launch": r["algo_flops"] / r["launches"]})
@@ -368,20 +416,31 @@ def main():
             roof["traffic_source"] = traffic_source
             roof["empty_event_pair_us"] = pair_us     # included in avg_launch_us (not subtracted): frac is a lower bound
             roof["measured"] = ("HIP events around every launch of the kernel, " +
-                                ("inside the timed region" if a.eager else
+                                ("inside the timed region" if eager else
                                  "eager pass over the same step right after the timed (graph-replayed) region, with the "
                                  "FPS + search launches of the replayed step issued as their separate entry points"))
-        line = {
-            "metric": metric, "value": clouds / elapsed,
-            "unit": "point-clouds/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": dt, "data": "synthetic",
-            "config": {"workload": workload, "name": a.config, "points": npoint, "batch_per_gpu": batch,
-                       "global_batch": batch * world, "parallelism": "dp%d" % world,
-                       "launch": "eager" if a.eager else "hipgraph"},
-            "roofline": roof,
-            "roofline_other_kernels": kernels[1:],
-        }
+        if not headline:
+            line = {"metric": w["metric"], "value": clouds / elapsed, "unit": "point-clouds/s", "steps": steps,
+                    "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "dtype": dt,
+                    "config": {"workload": w["workload"], "name": name, "points": npoint, "batch_per_gpu": batch,
+                               "launch": "hipgraph"},
+                    "roofline": roof,
+                    "roofline_other_kernels": [{k: r[k] for k in ("kernel", "bound", "achieved", "unit", "frac", "launches",
+                                                                  "avg_launch_us")} for r in kernels[1:]]}
+        else:
+            line = {
+                "metric": w["metric"], "value": clouds / elapsed,
+                "unit": "point-clouds/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+                "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": dt, "data": "synthetic",
+                "config": {"workload": w["workload"], "name": name, "points": npoint, "batch_per_gpu": batch,
+                           "global_batch": batch * world, "parallelism": "dp%d" % world,
+                           "launch": "eager" if eager else "hipgraph"},
+                "roofline": roof,
+                "roofline_other_kernels": kernels[1:],
+            }
+            if soak:
+                line["soak"] = soak
         fps_recs = [kt[n] for n in ("mpa_fps_knn_xyz_f32", "mpa_fps_f32") if kt.get(n) and kt[n]["launches"]]
         if fps_recs:
             # FPS is a chain of S dependent iterations per cloud (latency bound): iterations per second
@@ -398,15 +457,78 @@ def main():
             # SURVEY 8(d)'s unit for the grouping kernel: query x base-point distance evaluations (each over the
             # launch's C channels: xyz searches have C = 3, feature-space searches C = 64..256)
             line["knn"] = {"distance_evals_per_s": kn["algo_units"] / (kn["ms"] / 1e3),
-                           "distance_evals_per_step": kn["algo_units"] / min(a.steps, 10) if not a.eager else
-                           kn["algo_units"] / a.steps,
-                           "launches_per_step": kn["launches"] / (min(a.steps, 10) if not a.eager else a.steps),
-                           "ms_per_step": kn["ms"] / (min(a.steps, 10) if not a.eager else a.steps)}
-        if world == 1 and not a.eager and not a.no_forward_only:
-            line["forward_only"] = forward_only(run_forward, graphed.feeder, graphed.arena, batch)
-        if world == 1 and not a.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(task, batch if task == "cls" else min(batch, 4), npoint,
-                                                steps=3 if task == "cls" else 2)
+                           "distance_evals_per_step": kn["algo_units"] / n_timed_passes,
+                           "launches_per_step": kn["launches"] / n_timed_passes,
+                           "ms_per_step": kn["ms"] / n_timed_passes}
+        if world == 1 and not eager and not a.no_forward_only:
+            line["forward_only"] = forward_only(w["run_forward"], graphed.feeder, graphed.arena, batch,
+                                                iters=50 if headline else 10)
+    # release the configuration: graphs, pools and the FPS hook (the next configuration builds its own)
+    if graphed is not None:
+        graphed.close()
+    ops.clear_knn_memo()
+    ops.set_feature_dtype(old_dtype)
+    del graphed, model, crit, data, w, step
+    gc.collect()
+    torch.cuda.empty_cache()
+    return line
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="cls-fp32")
+    ap.add_argument("--batch", type=int, default=0, help="clouds per GPU (default: the configuration's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-forward-only", action="store_true", help="skip the secondary forward-only leg (profiling runs)")
+    ap.add_argument("--no-others", action="store_true", help="skip the other configurations after the headline")
+    ap.add_argument("--others", action="store_true", help="time the other configurations even with a non-default --config")
+    ap.add_argument("--soak", type=int, default=400, help="extra replayed steps of the headline after the timed region (0: none)")
+    ap.add_argument("--eager", action="store_true", help="launch every kernel from Python (no HIP graph)")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
+    local = local % torch.cuda.device_count()      # (rehearsals may stack ranks on one card)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    import mpa_amd  # noqa: F401
+    from mpa_amd import distributed as mdist
+
+    if world > 1:
+        mdist.init_process_group(os.environ.get("MPA_DIST_BACKEND"))
+    default_run = a.config == "cls-fp32" and not a.eager and not a.batch
+    if not default_run:
+        a.soak = 0 if "--soak" not in sys.argv else a.soak
+    line = run_config(a.config, a, world, rank, dev, a.steps, a.warmup, headline=True)
+    if rank == 0:
+        task = CONFIGS[a.config][0]
+        if world == 1 and not a.no_cpu_baseline and task in ("cls", "partseg", "s3dis"):
+            if task == "cls":
+                batch = a.batch or CONFIGS[a.config][3]
+                line["cpu_baseline"] = cpu_baseline(task, batch, CONFIGS[a.config][2], warm=2, steps=8)
+                # BASELINE configs[0]: the reference's own CPU-runnable case, batch 16 (3 warm-up + 10 timed)
+                c0 = cpu_baseline(task, 16, CONFIGS[a.config][2], warm=3, steps=10)
+                line["cpu_baseline"]["configs0_batch16"] = {k: c0[k] for k in ("value", "unit", "forward_only_value", "sample")}
+            else:
+                line["cpu_baseline"] = cpu_baseline(task, 2 if task == "s3dis" else 4, CONFIGS[a.config][2], warm=1, steps=2)
+        if world == 1 and ((default_run and not a.no_others) or a.others):
+            others = {}
+            for name in OTHER_CONFIGS:
+                if name == a.config:
+                    continue
+                try:
+                    others[name] = run_config(name, a, 1, 0, dev, steps=10, warmup=3, headline=False)
+                except Exception as e:          # a secondary configuration must never cost the headline line
+                    log("other config %s failed: %r" % (name, e))
+                    others[name] = {"error": repr(e)}
+            line["other_configs"] = others
         print(json.dumps(line), flush=True)
     mdist.shutdown()
 

@@ -36,6 +36,11 @@ extern "C" {
 /* bfloat16 storage (the upper 16 bits of an IEEE fp32, round-to-nearest-even on conversion) */
 typedef uint16_t mpa_bf16;
 
+/* ABI version: bumped whenever an exported signature changes incompatibly.  100 = round 1; 200 = round 2 (mpa_gemm_f32
+ * gained `stats_replicas`, mpa_adam_step_f32 gained `hyper`); 300 = round 3.  A binding must compare mpa_version()
+ * with the MPA_ABI_VERSION of the header it was written against and refuse a mismatch (the Python binding does,
+ * markov-process-analysis-on-point-cloud_amd/_lib.py). */
+#define MPA_ABI_VERSION 300
 int mpa_version(void);
 const char *mpa_error_string(int code);
 /* the hipError_t (and its text) behind the calling thread's most recent MPA_EHIP */
@@ -317,7 +322,8 @@ int mpa_upsample_mean_bwd_f32(const float *grad_out, const int64_t *knn_idx, con
 
 /* Global max over the points of a state: out[b][c] = max_n x[b][n][c], arg[b][c] = the first row attaining it
  * (`t.max(dim=1, keepdim=True)[0]` of the part-seg head, modules/pointnet2_utils.py:846-850), and its backward
- * grad_x[b][n][c] = (n == arg[b][c]) ? grad_out[b][c] : 0 (fully written).  NaNs are never selected. */
+ * grad_x[b][n][c] = (n == arg[b][c]) ? grad_out[b][c] : 0 (fully written).  A NaN in a column is propagated (arg = its
+ * first NaN row), as torch.max does. */
 int mpa_max_points_fwd_f32(const float *x, int B, int N, int C, float *out, int *arg, void *stream);
 int mpa_max_points_bwd_f32(const float *grad_out, const int *arg, int B, int N, int C, float *grad_x, void *stream);
 /* ---- PointNetFeaturePropagation interpolation: modules/pointnet2_utils.py:899-906.
@@ -327,6 +333,13 @@ int mpa_three_interp_fwd_f32(const float *points2, const int64_t *idx, const flo
                              int B, int Nq, int Nb, int C, float *out, void *stream);
 int mpa_three_interp_bwd_f32(const float *grad_out, const int64_t *idx, const float *dist,
                              int B, int Nq, int Nb, int C, float *grad_points2, void *stream);
+/* the same on bf16 features (north_star: "the matching upsample/interpolate decoder" on the bf16 feature stream):
+ * weights and sums in fp32, one rounding per output; the backward adds into a CLEARED fp32 grad_points2 (rows are
+ * listed by several query points), which the caller rounds once. */
+int mpa_three_interp_fwd_bf16(const mpa_bf16 *points2, const int64_t *idx, const float *dist,
+                              int B, int Nq, int Nb, int C, mpa_bf16 *out, void *stream);
+int mpa_three_interp_bwd_bf16(const mpa_bf16 *grad_out, const int64_t *idx, const float *dist,
+                              int B, int Nq, int Nb, int C, float *grad_points2, void *stream);
 
 /* ---- optimizer step over flat buckets (the training loop of tool/train_cls_scanobjectnn.py:205-216
  * uses torch.optim.Adam; gradients here live in a few flat buffers, so one elementwise pass per

@@ -125,6 +125,8 @@ SIGNATURES.update({
     "mpa_upsample_mean_fwd_bf16": SIGNATURES["mpa_upsample_mean_fwd_f32"],
     "mpa_upsample_mean_bwd_bf16": SIGNATURES["mpa_upsample_mean_bwd_f32"],
     "mpa_group_col_sum_bf16": SIGNATURES["mpa_group_col_sum_f32"],
+    "mpa_three_interp_fwd_bf16": SIGNATURES["mpa_three_interp_fwd_f32"],
+    "mpa_three_interp_bwd_bf16": SIGNATURES["mpa_three_interp_bwd_f32"],
 })
 
 for _name, _args in SIGNATURES.items():
@@ -135,6 +137,12 @@ lib.mpa_diffattn_bwd_workspace_bytes.restype = ctypes.c_size_t
 lib.mpa_diffattn_bwd_workspace_bytes_bf16.restype = ctypes.c_size_t
 lib.mpa_upsample_workspace_bytes.restype = ctypes.c_size_t
 lib.mpa_version.restype = ctypes.c_int
+# the argument lists above are written against this ABI version of include/mpa_hip.h (MPA_ABI_VERSION): a stale
+# library would take shifted arguments (a stream pointer read as a device array), so refuse it at load time
+ABI_VERSION = 300
+if lib.mpa_version() != ABI_VERSION:
+    raise ImportError("libmpa_hip.so reports ABI version %d, this binding expects %d -- rebuild it "
+                      "(make -C markov-process-analysis-on-point-cloud_amd/csrc)" % (lib.mpa_version(), ABI_VERSION))
 lib.mpa_error_string.restype = ctypes.c_char_p
 lib.mpa_error_string.argtypes = [ctypes.c_int]
 lib.mpa_last_hip_error.restype = ctypes.c_int

@@ -5,7 +5,9 @@ static thread_local int g_last_hip_error = 0;
 
 void mpa_note_hip_error(int hip_error) { g_last_hip_error = hip_error; }
 
-extern "C" int mpa_version(void) { return 100; }
+// MPA_ABI_VERSION of include/mpa_hip.h: bumped whenever an exported signature changes incompatibly (200: round 2
+// added `stats_replicas` to mpa_gemm_f32 and `hyper` to mpa_adam_step_f32; 300: round 3's entry points)
+extern "C" int mpa_version(void) { return MPA_ABI_VERSION; }
 
 extern "C" int mpa_last_hip_error(void) { return g_last_hip_error; }
 

@@ -236,9 +236,10 @@ __device__ __forceinline__ void interp_weights(const float *d, float w[3])
     w[0] = r0 / nrm; w[1] = r1 / nrm; w[2] = r2 / nrm;
 }
 
-__global__ void interp_fwd_kernel(const float *__restrict__ points2, const int64_t *__restrict__ idx,
+template <typename T>
+__global__ void interp_fwd_kernel(const T *__restrict__ points2, const int64_t *__restrict__ idx,
                                   const float *__restrict__ dist, int Nq, int Nb, int C, long long total,
-                                  float *__restrict__ out)
+                                  T *__restrict__ out)
 {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
@@ -248,15 +249,18 @@ __global__ void interp_fwd_kernel(const float *__restrict__ points2, const int64
         float w[3];
         interp_weights(dist + row * 3, w);
         const int64_t *id = idx + row * 3;
-        const float *p = points2 + (long long)b * Nb * C + c;
-        float acc = p[mpa_clamp_idx(id[0], Nb) * C] * w[0];
-        acc += p[mpa_clamp_idx(id[1], Nb) * C] * w[1];
-        acc += p[mpa_clamp_idx(id[2], Nb) * C] * w[2];
-        out[i] = acc;
+        const T *p = points2 + (long long)b * Nb * C + c;
+        float acc = mpa_ld1<T>(p + mpa_clamp_idx(id[0], Nb) * C) * w[0];
+        acc += mpa_ld1<T>(p + mpa_clamp_idx(id[1], Nb) * C) * w[1];
+        acc += mpa_ld1<T>(p + mpa_clamp_idx(id[2], Nb) * C) * w[2];
+        mpa_st1<T>(out + i, acc);
     }
 }
 
-__global__ void interp_bwd_kernel(const float *__restrict__ grad_out, const int64_t *__restrict__ idx,
+// gradients are summed in fp32 whatever the storage type of the incoming gradient (rows are listed by several
+// query points: float atomics on a cleared fp32 buffer; the bf16 caller rounds once afterwards)
+template <typename T>
+__global__ void interp_bwd_kernel(const T *__restrict__ grad_out, const int64_t *__restrict__ idx,
                                   const float *__restrict__ dist, int Nq, int Nb, int C, long long total,
                                   float *__restrict__ grad_points2)
 {
@@ -269,7 +273,7 @@ __global__ void interp_bwd_kernel(const float *__restrict__ grad_out, const int6
         interp_weights(dist + row * 3, w);
         const int64_t *id = idx + row * 3;
         float *p = grad_points2 + (long long)b * Nb * C + c;
-        float g = grad_out[i];
+        float g = mpa_ld1<T>(grad_out + i);
         atomicAdd(p + mpa_clamp_idx(id[0], Nb) * C, g * w[0]);
         atomicAdd(p + mpa_clamp_idx(id[1], Nb) * C, g * w[1]);
         atomicAdd(p + mpa_clamp_idx(id[2], Nb) * C, g * w[2]);
@@ -492,8 +496,8 @@ extern "C" int mpa_upsample_mean_bwd_bf16(const mpa_bf16 *grad_out, const int64_
 // (`x.max(dim=1)` of the part-seg head, reference modules/pointnet2_utils.py:846-850).  torch's own reduction is a
 // multi-workgroup kernel that mis-replays under HIP-graph capture on this stack and had to be taken in two stages
 // (20 us each on [32,2048,64]); here a workgroup of 64 row lanes x 16 channel lanes owns 16 channels of a cloud, every
-// lane walks N/64 rows with 8 loads in flight and the 64 partial (value, row) pairs meet in LDS.  NaNs are never
-// selected (an all-NaN column returns -inf, row 0).
+// lane walks N/64 rows with 8 loads in flight and the 64 partial (value, row) pairs meet in LDS.  A NaN in a
+// column is propagated (the first NaN row is the arg), as torch.max does: a diverged run shows up in the loss.
 namespace {
 constexpr int MAXP_RL = 64, MAXP_CL = 16;
 
@@ -516,11 +520,11 @@ __global__ __launch_bounds__(MAXP_RL * MAXP_CL) void max_points_fwd_kernel(const
             for (int u = 0; u < 8; ++u) v[u] = mpa_ld1<T>(p + (size_t)(n + u * MAXP_RL) * C);
 #pragma unroll
             for (int u = 0; u < 8; ++u)
-                if (v[u] > best) { best = v[u]; bi = n + u * MAXP_RL; }
+                if (v[u] > best || (v[u] != v[u] && best == best)) { best = v[u]; bi = n + u * MAXP_RL; }
         }
         for (; n < N; n += MAXP_RL) {
             const float v = mpa_ld1<T>(p + (size_t)n * C);
-            if (v > best) { best = v; bi = n; }
+            if (v > best || (v != v && best == best)) { best = v; bi = n; }
         }
     }
     sv[rl][cl] = best;
@@ -530,7 +534,9 @@ __global__ __launch_bounds__(MAXP_RL * MAXP_CL) void max_points_fwd_kernel(const
         for (int r = 1; r < MAXP_RL; ++r) {
             const float v = sv[r][cl];
             const int i2 = si[r][cl];
-            if (v > best || (v == best && i2 < bi)) { best = v; bi = i2; }
+            // a NaN is sticky (torch.max propagates it, reference :846-850); among equals / NaNs the lowest row wins
+            const bool vn = v != v, bn = best != best;
+            if ((vn && (!bn || i2 < bi)) || (!vn && !bn && (v > best || (v == best && i2 < bi)))) { best = v; bi = i2; }
         }
         mpa_st1<T>(out + (size_t)b * C + c, best);
         arg[(size_t)b * C + c] = bi;
@@ -598,26 +604,56 @@ extern "C" int mpa_max_points_bwd_bf16(const mpa_bf16 *grad_out, const int *arg,
                                       reinterpret_cast<bf16_t *>(grad_x), stream);
 }
 
-extern "C" int mpa_three_interp_fwd_f32(const float *points2, const int64_t *idx, const float *dist, int B, int Nq,
-                                        int Nb, int C, float *out, void *stream)
+namespace {
+template <typename T>
+int three_interp_fwd_any(const T *points2, const int64_t *idx, const float *dist, int B, int Nq, int Nb, int C, T *out,
+                         void *stream)
 {
     MPA_CLEAR_ERROR();
     if (!points2 || !idx || !dist || !out || B <= 0 || Nq <= 0 || Nb <= 0 || C <= 0) return MPA_EINVAL;
     long long total = (long long)B * Nq * C;
-    hipLaunchKernelGGL(interp_fwd_kernel, dim3(grid_for(total)), dim3(TPB), 0, (hipStream_t)stream, points2, idx, dist,
+    hipLaunchKernelGGL(interp_fwd_kernel<T>, dim3(grid_for(total)), dim3(TPB), 0, (hipStream_t)stream, points2, idx, dist,
                        Nq, Nb, C, total, out);
     MPA_LAUNCH_CHECK();
     return MPA_OK;
 }
 
-extern "C" int mpa_three_interp_bwd_f32(const float *grad_out, const int64_t *idx, const float *dist, int B, int Nq,
-                                        int Nb, int C, float *grad_points2, void *stream)
+template <typename T>
+int three_interp_bwd_any(const T *grad_out, const int64_t *idx, const float *dist, int B, int Nq, int Nb, int C,
+                         float *grad_points2, void *stream)
 {
     MPA_CLEAR_ERROR();
     if (!grad_out || !idx || !dist || !grad_points2 || B <= 0 || Nq <= 0 || Nb <= 0 || C <= 0) return MPA_EINVAL;
     long long total = (long long)B * Nq * C;
-    hipLaunchKernelGGL(interp_bwd_kernel, dim3(grid_for(total)), dim3(TPB), 0, (hipStream_t)stream, grad_out, idx,
+    hipLaunchKernelGGL(interp_bwd_kernel<T>, dim3(grid_for(total)), dim3(TPB), 0, (hipStream_t)stream, grad_out, idx,
                        dist, Nq, Nb, C, total, grad_points2);
     MPA_LAUNCH_CHECK();
     return MPA_OK;
+}
+}  // namespace
+
+extern "C" int mpa_three_interp_fwd_f32(const float *points2, const int64_t *idx, const float *dist, int B, int Nq,
+                                        int Nb, int C, float *out, void *stream)
+{
+    return three_interp_fwd_any<float>(points2, idx, dist, B, Nq, Nb, C, out, stream);
+}
+
+extern "C" int mpa_three_interp_bwd_f32(const float *grad_out, const int64_t *idx, const float *dist, int B, int Nq,
+                                        int Nb, int C, float *grad_points2, void *stream)
+{
+    return three_interp_bwd_any<float>(grad_out, idx, dist, B, Nq, Nb, C, grad_points2, stream);
+}
+
+extern "C" int mpa_three_interp_fwd_bf16(const mpa_bf16 *points2, const int64_t *idx, const float *dist, int B, int Nq,
+                                         int Nb, int C, mpa_bf16 *out, void *stream)
+{
+    return three_interp_fwd_any<bf16_t>(reinterpret_cast<const bf16_t *>(points2), idx, dist, B, Nq, Nb, C,
+                                        reinterpret_cast<bf16_t *>(out), stream);
+}
+
+extern "C" int mpa_three_interp_bwd_bf16(const mpa_bf16 *grad_out, const int64_t *idx, const float *dist, int B, int Nq,
+                                         int Nb, int C, float *grad_points2, void *stream)
+{
+    return three_interp_bwd_any<bf16_t>(reinterpret_cast<const bf16_t *>(grad_out), idx, dist, B, Nq, Nb, C, grad_points2,
+                                        stream);
 }

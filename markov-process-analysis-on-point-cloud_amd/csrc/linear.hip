@@ -1372,6 +1372,13 @@ inline void slab_grid(int M, int C, dim3 &grid, int &cpb, int &rows_per_block)
 // forward declaration (defined with the other column reductions below)
 static int launch_col_stats(const float *x, int M, int C, float *col_sum, float *col_sumsq, hipStream_t st);
 
+namespace {
+__global__ __launch_bounds__(256) void clear_f32_kernel(float *__restrict__ p, long long n)
+{
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (long long)gridDim.x * 256) p[i] = 0.f;
+}
+}  // namespace
+
 extern "C" int mpa_gemm_f32(const float *A, int lda, int transA, const float *B, int ldb, int transB,
                             const float *bias, float *C, int ldc, int M, int N, int K, int accumulate,
                             float *tile_stats, int stats_replicas, float *a_col_sum, float *workspace,
@@ -1437,7 +1444,13 @@ extern "C" int mpa_gemm_f32(const float *A, int lda, int transA, const float *B,
             dst = workspace;
             reduce_after = true;
         } else {
-            if (!accumulate && hipMemsetAsync(C, 0, sizeof(float) * mn, st) != hipSuccess) return MPA_EHIP;
+            if (!accumulate) {
+                // a plain kernel, not hipMemsetAsync: no memset nodes inside a captured HIP graph (as gather.hip, diffattn.hip)
+                const long long n = (long long)mn;
+                long long g = (n + 255) / 256;
+                hipLaunchKernelGGL(clear_f32_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, st, C, n);
+                MPA_LAUNCH_CHECK();
+            }
             out_mode = 1;
         }
     }

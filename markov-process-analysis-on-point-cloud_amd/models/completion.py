@@ -17,7 +17,7 @@ Geometry: the clouds of a batch arrive in SAMPLING ORDER -- the S-point prefix o
 points (`sampling_order()` below produces that order with one farthest_point_sample(x, N) call per batch, the
 offline FPS of dataset/ModelNetDataLoader.py:47-78 applied to the dense shape) -- so the five nested states are
 prefixes and no FPS runs inside the step.  Parity: every op and block is pinned on its own (tests/test_gpu_ops.py,
-test_gpu_blocks.py) and each LocalMerge at 8192 / 16,384 rows against oracle/ref_cpu.py
+test_gpu_blocks.py) and each LocalMerge at 8192 / 16,384 rows against the CPU restatement of the reference
 (tests/test_gpu_full_size.py); the wiring itself has no reference counterpart ("parity unpinned beyond op level").
 """
 import torch

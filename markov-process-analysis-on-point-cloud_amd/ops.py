@@ -289,6 +289,14 @@ def _memo_put(base, query, k, dist, idx):
     del _XYZ_KNN_MEMO[:-_XYZ_KNN_MEMO_SIZE]
 
 
+def clear_knn_memo():
+    """Forget the remembered coordinate searches.  The memo is scoped to ONE forward pass (GeometryChain and
+    GraphedTrainStep clear it when a pass starts): its key is (address, torch version counter, shape), and a
+    coordinate buffer rewritten through a raw-pointer launch or `.data` keeps both -- callers must not rely on the
+    memo for persistent buffers that change between passes."""
+    del _XYZ_KNN_MEMO[:]
+
+
 def knn_point(nsample, xyz, new_xyz):
     """reference: modules/pointnet2_utils.py:211-222.  Returns (dist [B,S,k], idx int64 [B,S,k]),
     ascending.  Indices are not differentiable; dist carries no gradient (the models never use it)."""
@@ -451,6 +459,7 @@ class GeometryChain:
 
     def __init__(self, xyz, npoints, k):
         _dev(xyz)
+        clear_knn_memo()                 # a new forward pass: searches remembered from an earlier one never match
         self.npoints, self.k = tuple(npoints), k
         g = _GeoLevel()
         g.xyz, g.chain, g.i = xyz, self, 0
@@ -793,8 +802,8 @@ class _ThreeInterp(torch.autograd.Function):
     def forward(ctx, points2, idx, dist):
         B, Nb, C = points2.shape
         Nq = idx.shape[1]
-        out = torch.empty(B, Nq, C, dtype=torch.float32, device=points2.device)
-        _launch("mpa_three_interp_fwd_f32", _p(points2), _p(idx), _p(dist), B, Nq, Nb, C, _p(out), _stream())
+        out = torch.empty(B, Nq, C, dtype=points2.dtype, device=points2.device)
+        _launch("mpa_three_interp_fwd_" + _sfx(points2), _p(points2), _p(idx), _p(dist), B, Nq, Nb, C, _p(out), _stream())
         ctx.save_for_backward(idx, dist)
         ctx.shape = (B, Nq, Nb, C)
         return out
@@ -804,19 +813,21 @@ class _ThreeInterp(torch.autograd.Function):
         idx, dist = ctx.saved_tensors
         B, Nq, Nb, C = ctx.shape
         grad = grad.contiguous()
+        # coarse rows are listed by several fine points: summed in fp32 (float atomics), rounded once for bf16 features
         gp = torch.zeros(B, Nb, C, dtype=torch.float32, device=grad.device)
-        _launch("mpa_three_interp_bwd_f32", _p(grad), _p(idx), _p(dist), B, Nq, Nb, C, _p(gp), _stream())
-        return gp, None, None
+        _launch("mpa_three_interp_bwd_" + _sfx(grad), _p(grad), _p(idx), _p(dist), B, Nq, Nb, C, _p(gp), _stream())
+        return (gp if grad.dtype == torch.float32 else gp.to(grad.dtype)), None, None
 
 
 def three_interpolate(xyz1, xyz2, points2):
     """Inverse-distance 3-NN interpolation of PointNetFeaturePropagation
-    (modules/pointnet2_utils.py:896-906): xyz1 [B,N,3] fine, xyz2 [B,S,3] coarse, points2 [B,S,D]."""
+    (modules/pointnet2_utils.py:896-906): xyz1 [B,N,3] fine, xyz2 [B,S,3] coarse, points2 [B,S,D] (fp32 or bf16
+    features: the interpolated rows stay in the feature stream's storage type)."""
     _dev(xyz1, xyz2, points2)
     if xyz2.shape[1] == 1:
         return points2.repeat(1, xyz1.shape[1], 1)
     dist, idx = three_nn(xyz1, xyz2)
-    return _ThreeInterp.apply(_f32(points2), idx, dist)
+    return _ThreeInterp.apply(_feat(points2), idx, dist)
 
 
 class _MaxOverPoints(torch.autograd.Function):

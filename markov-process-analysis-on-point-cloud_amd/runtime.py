@@ -159,6 +159,7 @@ class GraphedTrainStep:
             self.reducer.start(self.reducer.early)
 
     def _fwd_bwd(self):
+        ops.clear_knn_memo()
         self.feeder.begin_pass()
         self.reducer.zero_grad()
         self.arena.begin()
