@@ -124,7 +124,10 @@ class GraphedTrainStep:
         # overlaps the rest of backward instead of running after the replay.
         self.reducer = GradReducer(model, bucket_bytes=bucket_bytes, direct=True, split_after=split_after)
         self.reducer.overlap = False
-        self.capture_reduce = bool(capture_reduce) and is_dist() and world_size() > 1
+        # (MPA_CAPTURE_REDUCE_SINGLE_RANK=1: also on a one-rank group -- the captured RCCL collective then runs on a
+        # single GPU, which is how tests/test_gpu_rccl_capture.py exercises this path on a one-GPU box)
+        self.capture_reduce = bool(capture_reduce) and is_dist() and (
+            world_size() > 1 or os.environ.get("MPA_CAPTURE_REDUCE_SINGLE_RANK") == "1")
         if split_after is not None:
             self.reducer.on_split = self._on_split
         ops.set_fps_start_hook(self.feeder)

@@ -261,6 +261,36 @@ def test_diffattn_xyz_bf16(ops):
 
 
 # ------------------------------------------------------------------------------------------ the Linear unit and blocks
+def test_three_interpolate_bf16_twin(ops, golden_blocks):
+    """mpa_three_interp_{fwd,bwd}_bf16 (north_star's "interpolate" decoder on the bf16 feature stream, reference
+    modules/pointnet2_utils.py:896-906): forward equals the fp32 kernel on the bf16-rounded rows, rounded once (bit for
+    bit: same fp32 arithmetic); the backward sums in fp32 like its twin (float atomics: equal to accumulation order,
+    then one rounding); PointNetFeaturePropagation stays on the bf16 stream end to end and matches the reference's
+    fp32 fixture at the bf16 storage tolerance."""
+    from mpa_amd.modules import pointnet2_utils as P
+    B, N, S, D = 3, 700, 150, 48
+    x1, x2 = unit_cloud(B, N, seed=1).cuda(), unit_cloud(B, S, seed=2).cuda()
+    p16 = randn((B, S, D), seed=3).to(BF).cuda().requires_grad_(True)
+    p32 = p16.detach().float().requires_grad_(True)
+    o16, o32 = ops.three_interpolate(x1, x2, p16), ops.three_interpolate(x1, x2, p32)
+    assert o16.dtype == BF and torch.equal(o16, o32.to(BF))
+    w = randn((B, N, D), seed=4).to(BF).cuda()
+    o16.backward(w)
+    o32.backward(w.float())
+    assert p16.grad.dtype == BF
+    assert rel_l2(p16.grad.float(), p32.grad) < 4e-3                      # one bf16 rounding of equal fp32 sums
+    assert (p16.grad.float() - p32.grad.to(BF).float()).abs().max() <= 2 ** -7 * p32.grad.abs().max()
+    g = golden_blocks
+    xyz, fps = G(g["geo/xyz"]), GL(g["geo/fps"])
+    sub = P.index_points(xyz, fps)
+    m = fill_state(P.PointNetFeaturePropagation(32, [48], act=True), seed=5).cuda().train()
+    pts2 = G(g["fp/points2"]).to(BF).requires_grad_(True)
+    out = m(xyz, sub, None, pts2)
+    assert out.dtype == BF and rel_l2(out.float(), G(g["fp/out"])) < 1.5e-2
+    out.backward(randn(out.shape, seed=4242).cuda().to(BF))
+    assert pts2.grad.dtype == BF and rel_l2(pts2.grad.float(), G(g["fp/gpoints2"])) < 3e-2
+
+
 def test_linear_unit_bf16_against_fp32_fixture(golden_blocks):
     """reference Linear (Linear -> BatchNorm1d over the rows -> LeakyReLU) in bf16 against the reference's own fp32
     outputs and gradients (tests/golden/blocks.npz): tolerance = the precision's cost, stated here: 1.5e-2 relative
@@ -310,6 +340,32 @@ def test_local_merge_bf16_against_fp32_fixture(golden_blocks):
             f1.backward(randn(f1.shape, seed=4242).cuda().to(BF))
             # (the max over K re-routes gradient wherever bf16 rounding flips a near-tied selection: measured 5-9e-2)
             assert rel_l2(feat.grad.float(), G(g[tag + "/gfeat"])) < 0.15, tag
+        # every parameter gradient of the block against the fp32 HIP path on the SAME bf16-rounded input and the same
+        # neighbourhoods (not only gradient norms: a wrong bf16 dW of a single unit shows up here)
+        m32 = fill_state(cls(64, 64, 8, usetanh=False, residual=False), seed=4).cuda().train()
+        feat32 = G(g[tag + "/f0"]).to(BF).float().requires_grad_(True)
+        forced = [GL(g[tag + "/idx1"]), GL(g[tag + "/idx1_feat"])]
+        try:
+            P.knn_point = RS.knn_point = lambda k, a, b: (None, forced.pop(0))
+            f32 = m32(xyz=sub, base_xyz=xyz, normal=xyz, feature=feat32, FPS_idx=fps)[0]
+        finally:
+            P.knn_point = RS.knn_point = real
+        f32.backward(randn(f32.shape, seed=4242).cuda().to(BF).float())
+        assert rel_l2(f1.float(), f32) < 2e-2, tag
+        assert rel_l2(feat.grad.float(), feat32.grad) < 0.12, tag
+        # error of every parameter's gradient tensor relative to its own norm -- or, for the gradients that are
+        # cancelling sums (q projections: softmax_j(q - k_j) does not depend on q at all, so dL/dWq is identically zero in
+        # exact arithmetic and pure rounding noise in fp32; biases summed over all rows), to 5 % of the block's largest
+        worst = {}
+        top = max(float(p32.grad.double().norm()) for p32 in m32.parameters() if p32.grad is not None)
+        for (n16, p16), (n32, p32) in zip(m1.named_parameters(), m32.named_parameters()):
+            if p32.grad is None or float(p32.grad.abs().max()) == 0:
+                continue
+            assert p16.grad is not None and p16.grad.dtype == torch.float32, n16
+            den = max(float(p32.grad.double().norm()), 0.05 * top)
+            worst[n16] = float((p16.grad.double() - p32.grad.double()).norm()) / den
+        print(tag, "bf16 vs fp32-HIP parameter gradients, worst:", sorted(worst.items(), key=lambda kv: -kv[1])[:4])
+        assert max(worst.values()) < 0.12, (tag, sorted(worst.items(), key=lambda kv: -kv[1])[:4])
 
 
 def test_partseg_model_bf16_against_fp32_fixture(golden_seg):

@@ -490,6 +490,28 @@ def test_max_over_points_matches_torch(ops, B, N, C, dtype):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_max_over_points_propagates_nan(ops, dtype):
+    """x.max(dim=1) propagates NaN (reference modules/pointnet2_utils.py:846-850): a column holding a NaN returns NaN
+    with the gradient routed to its first NaN row, an all-NaN column likewise; clean columns are untouched -- a
+    diverged run must show up in the loss instead of as finite global features."""
+    B, N, C = 2, 700, 24
+    x = torch.randn(B, N, C, generator=torch.Generator().manual_seed(1)).to(dtype)
+    x[0, 650, 3] = float("nan")            # one NaN late in a column
+    x[0, 10, 3] = float("nan")             # ... and an earlier one: the first NaN row is the arg
+    x[1, :, 7] = float("nan")              # an all-NaN column
+    x = x.cuda().requires_grad_(True)
+    out = ops.max_over_points(x)
+    want = x.detach().float().cpu().max(dim=1, keepdim=True)[0]
+    assert torch.equal(torch.isnan(out.float().cpu()), torch.isnan(want))
+    ok = ~torch.isnan(want)
+    assert torch.equal(out.float().cpu()[ok], want[ok])
+    out.backward(torch.ones_like(out))
+    g = x.grad.float().cpu()
+    assert g[0, 10, 3] == 1 and g[0, :, 3].sum() == 1 and g[1, 0, 7] == 1 and g[1, :, 7].sum() == 1
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B,fN,fS,N,S,C,with_xyz", [(4, 512, 256, 1024, 512, 64, True), (40, 1024, 512, 2048, 1024, 64, True),
                                                      (3, 300, 77, 150, 90, 128, False), (2, 2048, 1000, 333, 333, 64, True),
                                                      (2, 100, 50, 200, 100, 64, True), (2, 512, 256, 300, 200, 32, True)])
