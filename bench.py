@@ -135,6 +135,7 @@ def forward_only(run_forward, feeder, arena, batch, iters=50):
     """Forward pass alone (train-mode BatchNorm statistics, no autograd), captured as a HIP graph: a
     secondary figure next to the headline fwd+bwd metric (SURVEY 8d states the >= 20x target on it)."""
     from mpa_amd import ops
+    saved_prefetch = ops.set_geometry_prefetch(None)       # forward alone: the sampling chain runs inside the pass
 
     def one_pass():
         feeder.begin_pass()
@@ -168,6 +169,7 @@ def forward_only(run_forward, feeder, arena, batch, iters=50):
             g.replay()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / iters
+    ops.set_geometry_prefetch(saved_prefetch)
     return {"value": batch / dt, "unit": "point-clouds/s", "ms_per_step": dt * 1e3, "steps": iters}
 
 
@@ -224,7 +226,11 @@ def build_workload(name, batch, rank, dev):
     task, dt, npoint, dbatch, which = CONFIGS[name]
     torch.manual_seed(0)
     data = synthetic_batch(task, batch, npoint, 1234 + rank, dev)
-    w = {"task": task, "dt": dt, "npoint": npoint, "batch": batch, "data": data, "compute_loss": None, "split": None}
+    # a second, distinct resident batch: steps alternate between the two, and each step announces the other as the next
+    # one (its sampling chain is computed a step ahead, inside this step's weight-gradient launches)
+    data2 = synthetic_batch(task, batch, npoint, 4321 + rank, dev)
+    w = {"task": task, "dt": dt, "npoint": npoint, "batch": batch, "data": data, "data2": data2, "compute_loss": None,
+         "split": None, "has_chain": task != "completion"}
     if task == "cls":
         from mpa_amd.models.repsurf.repsurf_ssg_umb import Model, SmoothClsLoss
         args = argparse.Namespace(num_point=npoint, return_dist=True, cuda_ops=True, num_class=NUM_CLASS)
@@ -310,11 +316,17 @@ def run_config(name, a, world, rank, dev, steps, warmup, headline):
         # all-reduce them INSIDE the captured graph, overlapped with the rest of backward.  Off by default: RCCL under
         # graph capture has run on one rank only (tests/test_gpu_rccl_capture.py), never across GPUs.
         cap = world > 1 and os.environ.get("MPA_CAPTURE_REDUCE") == "1" and w["split"] is not None
+        prefetch = w["has_chain"] and not cap and os.environ.get("MPA_NO_PREFETCH") is None
         graphed = GraphedTrainStep(model, crit, data, lr=1e-3, compute_loss=w["compute_loss"],
-                                   split_after=w["split"] if cap else None, capture_reduce=cap)   # optim.FlatAdam
+                                   split_after=w["split"] if cap else None, capture_reduce=cap,
+                                   prefetch_geometry=prefetch)                                    # optim.FlatAdam
+        pair = (data, w["data2"])
+        turn = [0]
 
-        def step():
-            return graphed(*data)
+        def step(announce=True):
+            cur, nxt = pair[turn[0] & 1], pair[(turn[0] + 1) & 1]
+            turn[0] += 1
+            return graphed(*cur, next_batch=nxt if announce else None)
 
     eager = a.eager and headline
     for _ in range(warmup):
@@ -352,6 +364,9 @@ def run_config(name, a, world, rank, dev, steps, warmup, headline):
         soak = {"steps": a.soak, "ms_per_step": dts / a.soak * 1e3, "value": batch * a.soak / dts, "unit": "point-clouds/s"}
         log("soak: %d steps, %.3f ms/step" % (a.soak, soak["ms_per_step"]))
     n_timed_passes = steps if eager else min(steps, 10 if headline else 3)
+    if not eager:
+        step(announce=False)        # untimed: leaves the static batch and the buffered geometry on the SAME batch
+        torch.cuda.synchronize()
     if not eager and rank == 0 and not cap:     # (with the all-reduce captured in the pass, rank 0 cannot run it alone)
         # A replayed HIP graph has no per-kernel event hooks: the kernels are timed live, with HIP
         # events on their launch stream, in an eagerly launched pass over the same step right
@@ -435,7 +450,12 @@ def run_config(name, a, world, rank, dev, steps, warmup, headline):
                 "vs_baseline": None, "dtype": dt, "data": "synthetic",
                 "config": {"workload": w["workload"], "name": name, "points": npoint, "batch_per_gpu": batch,
                            "global_batch": batch * world, "parallelism": "dp%d" % world,
-                           "launch": "eager" if eager else "hipgraph"},
+                           "launch": "eager" if eager else "hipgraph",
+                           "batches": "two distinct resident synthetic batches per rank, alternating every step (copied "
+                                      "into the graph's static buffers inside the timed region)" + (
+                               "; each step announces the next batch, whose FPS chain and first two coordinate searches "
+                               "run in this step's weight-gradient launches (ops.GeometryPrefetch)"
+                               if (graphed is not None and graphed.prefetch is not None) else "")},
                 "roofline": roof,
                 "roofline_other_kernels": kernels[1:],
             }

@@ -242,6 +242,35 @@ typedef struct MpaGemmTnProblem {
 } MpaGemmTnProblem;
 int mpa_gemm_tn_grouped_f32(const MpaGemmTnProblem *problems, int count, float *workspace,
                             size_t workspace_bytes, void *stream);
+/* Geometry rider: sampling levels and one coordinate search of the NEXT batch, carried by the first workgroups of a
+ * long launch of the current step (cross-step co-scheduling of the FPS chain, which depends on coordinates only:
+ * modules/repsurface_utils.py:581-619, modules/pointnet2_utils.py:84-109, :211-222).
+ *   sampling (nlev in 0..4 levels, one workgroup per cloud runs them all in sequence):
+ *     level 0 samples S[0] points from src [B,N,3] (N <= 4096), level j > 0 samples S[j] <= S[j-1] points from level
+ *     j-1's result; start[j] [B], idx[j] [B,S[j]] int64, xyz[j] [B,S[j],3] as in mpa_fps_f32;
+ *   search (optional, base != NULL): knn_point(sK <= 8, base [B,sN,3], query [B,sS,3]) -> dist / kidx [B,sS,sK],
+ *     as mpa_knn_f32 with C = 3 (it must not depend on this rider's own sampling results).
+ * Results are bit-identical to the stand-alone entry points. */
+typedef struct MpaGeoRider {
+    const float *src;
+    int B, N, nlev;
+    int S[4];
+    const int64_t *start[4];
+    int64_t *idx[4];
+    float *xyz[4];
+    const float *base;
+    const float *query;
+    int sN, sS, sK;
+    float *dist;
+    int64_t *kidx;
+} MpaGeoRider;
+/* mpa_gemm_tn_grouped_f32 with riders: rider i travels in the i-th weight-gradient launch of the call (40 problems per
+ * launch), riders beyond the number of launches are issued afterwards as launches of their own, in order -- so a
+ * rider may consume the results of the riders before it.  `riders` is a HOST array. */
+int mpa_gemm_tn_grouped_rider_f32(const MpaGemmTnProblem *problems, int count, float *workspace,
+                                  size_t workspace_bytes, const MpaGeoRider *riders, int nriders, void *stream);
+/* one rider as a launch of its own (the first batch of a run, which has no previous step to ride in) */
+int mpa_geo_rider_f32(const MpaGeoRider *rider, void *stream);
 /* tile statistics (same format as the GEMM epilogue's) of an existing tensor x [M,C]. */
 int mpa_tile_stats_f32(const float *x, int M, int C, float *tile_stats, void *stream);
 /* per-column sum and sum of squares of x [M,C] -> col_sum, col_sumsq [C] (caller zeroes). */

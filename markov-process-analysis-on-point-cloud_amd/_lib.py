@@ -73,6 +73,18 @@ class GemmTnProblem(ctypes.Structure):
 SIGNATURES["mpa_gemm_tn_grouped_f32"] = [ctypes.POINTER(GemmTnProblem), _i, _vp, ctypes.c_size_t, _vp]
 
 
+class GeoRider(ctypes.Structure):
+    """struct MpaGeoRider of include/mpa_hip.h"""
+    _fields_ = [("src", _vp), ("B", _i), ("N", _i), ("nlev", _i), ("S", _i * 4), ("start", _vp * 4), ("idx", _vp * 4),
+                ("xyz", _vp * 4), ("base", _vp), ("query", _vp), ("sN", _i), ("sS", _i), ("sK", _i), ("dist", _vp),
+                ("kidx", _vp)]
+
+
+SIGNATURES["mpa_gemm_tn_grouped_rider_f32"] = [ctypes.POINTER(GemmTnProblem), _i, _vp, ctypes.c_size_t,
+                                               ctypes.POINTER(GeoRider), _i, _vp]
+SIGNATURES["mpa_geo_rider_f32"] = [ctypes.POINTER(GeoRider), _vp]
+
+
 class GemmProblem(ctypes.Structure):
     """struct MpaGemmProblem of include/mpa_hip.h"""
     _fields_ = [("A", _vp), ("B", _vp), ("bias", _vp), ("C", _vp), ("tile_stats", _vp),

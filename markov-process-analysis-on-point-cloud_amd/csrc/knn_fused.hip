@@ -88,15 +88,18 @@ extern "C" int mpa_fps_knn_feat_f32(const float *fps_xyz, int B, int fps_N, int 
                                     int S, int C, int K, float *out_dist, int64_t *out_idx, void *stream)
 {
     MPA_CLEAR_ERROR();
-    if (!fps_xyz || !start_idx || !fps_idx || !feat_base || !feat_query || !out_idx || B <= 0 || fps_N <= 0 ||
-        fps_S <= 0 || N <= 0 || S <= 0 || K <= 0)
-        return MPA_EINVAL;
+    // fps_xyz == NULL: no sampling workgroups -- the two searches of a state alone in one launch (the sampling chain
+    // of that pass was computed a step ahead by geometry riders, mpa_gemm_tn_grouped_rider_f32)
+    const bool sample = fps_xyz != nullptr;
+    if (!feat_base || !feat_query || !out_idx || B <= 0 || N <= 0 || S <= 0 || K <= 0) return MPA_EINVAL;
+    if (sample && (!start_idx || !fps_idx || fps_N <= 0 || fps_S <= 0)) return MPA_EINVAL;
     if (xyz_base && (!xyz_query || !xyz_idx || xN <= 0 || xS <= 0 || xK <= 0)) return MPA_EINVAL;
     // the instantiated combinations: FPS of 129..2048 points, K <= 8, feature rows of 64 / 128 floats, 16-byte aligned
-    if (K > 8 || K > N || (xyz_base && (xK > 8 || xK > xN)) || fps_N <= 128 || fps_N > 2048 || (C != 64 && C != 128) ||
-        ((((uintptr_t)feat_base | (uintptr_t)feat_query | (uintptr_t)feat_norms) & 15) != 0))
+    if (K > 8 || K > N || (xyz_base && (xK > 8 || xK > xN)) || (sample && (fps_N <= 128 || fps_N > 2048)) ||
+        (C != 64 && C != 128) || ((((uintptr_t)feat_base | (uintptr_t)feat_query | (uintptr_t)feat_norms) & 15) != 0))
         return MPA_EUNSUPPORTED;
-    const int P = fps_N <= 256 ? 1 : (fps_N <= 512 ? 2 : (fps_N <= 1024 ? 4 : 8));
+    const int P = !sample || fps_N <= 256 ? 1 : (fps_N <= 512 ? 2 : (fps_N <= 1024 ? 4 : 8));
+    const int fB = sample ? B : 0;               // sampling workgroups in front of the searches'
     FusedSearch x, y;
     x.base = xyz_base; x.query = xyz_query; x.norms = nullptr; x.dist = xyz_dist; x.idx = xyz_idx;
     x.N = xN; x.S = xS; x.K = xK; x.qb = xyz_base ? mpa_ceil_div(xS, 32) : 1; x.blocks = xyz_base ? x.qb * B : 0;
@@ -105,10 +108,10 @@ extern "C" int mpa_fps_knn_feat_f32(const float *fps_xyz, int B, int fps_N, int 
     hipStream_t st = (hipStream_t)stream;
     if (C == 64 && feat_norms != nullptr) {                      // two query groups per workgroup (needs the norms)
         y.qb = mpa_ceil_div(S, 64); y.blocks = y.qb * B;
-        return launch_fused_p<64, 2, true>(P, fps_xyz, B, fps_N, fps_S, start_idx, fps_idx, fps_out_xyz, x, y, st);
+        return launch_fused_p<64, 2, true>(P, fps_xyz, fB, fps_N, fps_S, start_idx, fps_idx, fps_out_xyz, x, y, st);
     }
     y.qb = mpa_ceil_div(S, 32); y.blocks = y.qb * B;
     y.norms = nullptr;
-    if (C == 64) return launch_fused_p<64, 1, false>(P, fps_xyz, B, fps_N, fps_S, start_idx, fps_idx, fps_out_xyz, x, y, st);
-    return launch_fused_p<128, 1, false>(P, fps_xyz, B, fps_N, fps_S, start_idx, fps_idx, fps_out_xyz, x, y, st);
+    if (C == 64) return launch_fused_p<64, 1, false>(P, fps_xyz, fB, fps_N, fps_S, start_idx, fps_idx, fps_out_xyz, x, y, st);
+    return launch_fused_p<128, 1, false>(P, fps_xyz, fB, fps_N, fps_S, start_idx, fps_idx, fps_out_xyz, x, y, st);
 }

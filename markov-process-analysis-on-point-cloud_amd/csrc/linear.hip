@@ -16,6 +16,7 @@
 #include "mpa_common.h"
 #include "mpa_bf16.h"
 #include "splitk_reduce.h"
+#include "geo_rider.h"
 #include <cstdlib>
 #include <type_traits>
 
@@ -469,17 +470,17 @@ struct GroupedArgs {
     GroupedProblem p[GROUP_MAX];
 };
 
-__global__ __launch_bounds__(NT, 2) void gemm_tn_grouped_kernel(const GroupedArgs args)
+__device__ __forceinline__ void tn_grouped_block(const GroupedArgs &args, const int bid)
 {
     __shared__ int which;
     if (threadIdx.x == 0) {
-        int b = blockIdx.x, i = 0;
+        int b = bid, i = 0;
         while (i + 1 < args.count && b >= args.block_start[i + 1]) ++i;
         which = i;
     }
     __syncthreads();
     const GroupedProblem &q = args.p[which];
-    const int local = blockIdx.x - args.block_start[which];
+    const int local = bid - args.block_start[which];
     const int tile = local % q.tiles, z = local / q.tiles;
     const int vecA = q.vec & 1, vecB = (q.vec >> 1) & 1;
     if (q.slab != nullptr)
@@ -488,6 +489,24 @@ __global__ __launch_bounds__(NT, 2) void gemm_tn_grouped_kernel(const GroupedArg
     else
         gemm_body<true, false>(tile, z, q.A, q.lda, q.B, q.ldb, nullptr, q.out, q.N, q.M, q.N, q.K, q.kchunk, 0, vecA,
                                vecB, nullptr, nullptr, q.a_col_sum, q.stream);
+}
+
+__global__ __launch_bounds__(NT, 2) void gemm_tn_grouped_kernel(const GroupedArgs args)
+{
+    tn_grouped_block(args, blockIdx.x);
+}
+
+// The same launch carrying a geometry rider (geo_rider.h): its first r.blocks workgroups sample / search the NEXT
+// batch's coordinates -- they are dispatched first and run for the length of the launch on one CU slot per cloud --
+// the others are the weight-gradient products.
+__global__ __launch_bounds__(NT, 2) void gemm_tn_grouped_rider_kernel(const GroupedArgs args, const RiderArgs r)
+{
+    extern __shared__ float lds[];
+    if ((int)blockIdx.x < r.blocks) {
+        rider_body(r, blockIdx.x, lds);
+        return;
+    }
+    tn_grouped_block(args, blockIdx.x - r.blocks);
 }
 
 // ---- grouped forward / dX products: a few INDEPENDENT  C_p = A_p op(B_p) (+ bias)  in one launch -- the Linear units
@@ -1487,12 +1506,30 @@ extern "C" int mpa_gemm_f32(const float *A, int lda, int transA, const float *B,
     return MPA_OK;
 }
 
+extern "C" int mpa_geo_rider_f32(const MpaGeoRider *rider, void *stream)
+{
+    MPA_CLEAR_ERROR();
+    if (!rider) return MPA_EINVAL;
+    const int rc = rider_launch_alone(*rider, (hipStream_t)stream);
+    if (rc != MPA_OK) return rc;
+    MPA_LAUNCH_CHECK();
+    return MPA_OK;
+}
+
 extern "C" int mpa_gemm_tn_grouped_f32(const MpaGemmTnProblem *problems, int count, float *workspace,
                                        size_t workspace_bytes, void *stream)
 {
+    return mpa_gemm_tn_grouped_rider_f32(problems, count, workspace, workspace_bytes, nullptr, 0, stream);
+}
+
+extern "C" int mpa_gemm_tn_grouped_rider_f32(const MpaGemmTnProblem *problems, int count, float *workspace,
+                                             size_t workspace_bytes, const MpaGeoRider *riders, int nriders,
+                                             void *stream)
+{
     MPA_CLEAR_ERROR();
-    if (!problems || count <= 0) return MPA_EINVAL;
+    if (!problems || count <= 0 || nriders < 0 || (nriders > 0 && !riders)) return MPA_EINVAL;
     hipStream_t st = (hipStream_t)stream;
+    int launch_no = 0;
     size_t ws_used = 0;
     int done = 0;
     // more problems than one launch's argument block holds: equal-sized launches, in queue order (dealing the
@@ -1564,8 +1601,29 @@ extern "C" int mpa_gemm_tn_grouped_f32(const MpaGemmTnProblem *problems, int cou
         }
         ga.count = n;
         ra.count = nr;
-        hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(blocks), dim3(NT), gemm_lds_bytes(true, false), st, ga);
+        if (launch_no < nriders) {
+            // this launch carries rider `launch_no` (riders are in dependency order: one per launch, in stream order)
+            RiderArgs rd;
+            size_t rlds = 0;
+            const int rc = rider_prepare(riders[launch_no], rd, rlds);
+            if (rc != MPA_OK) return rc;
+            size_t lds = gemm_lds_bytes(true, false);
+            if (rlds > lds) {
+                lds = rlds;
+                if (hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tn_grouped_rider_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                    return MPA_EHIP;
+            }
+            hipLaunchKernelGGL(gemm_tn_grouped_rider_kernel, dim3(blocks + rd.blocks), dim3(NT), lds, st, ga, rd);
+        } else {
+            hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(blocks), dim3(NT), gemm_lds_bytes(true, false), st, ga);
+        }
+        ++launch_no;
         if (nr > 0) hipLaunchKernelGGL(splitk_reduce_grouped_kernel, dim3(rblocks), dim3(256), 0, st, ra);
+    }
+    for (; launch_no < nriders; ++launch_no) {            // more riders than launches: the rest go out on their own
+        const int rc = rider_launch_alone(riders[launch_no], st);
+        if (rc != MPA_OK) return rc;
     }
     MPA_LAUNCH_CHECK();
     return MPA_OK;

@@ -109,7 +109,7 @@ class GraphedTrainStep:
 
     def __init__(self, model, loss_fn, example_batch, optimizer=None, lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
                  weight_decay=0.0, warmup=2, bucket_bytes=64 << 20, compute_loss=None, split_after=None,
-                 capture_reduce=False):
+                 capture_reduce=False, prefetch_geometry=False, coords_of=None):
         # compute_loss(model, loss_fn, *batch) -> scalar loss; default: loss_fn(model(batch[0]), *batch[1:])
         from .optim import FlatAdam
         self.model, self.loss_fn = model, loss_fn
@@ -131,11 +131,29 @@ class GraphedTrainStep:
         if split_after is not None:
             self.reducer.on_split = self._on_split
         ops.set_fps_start_hook(self.feeder)
+        # prefetch_geometry: the sampling chain + the first two coordinate searches of the NEXT batch are computed by
+        # geometry riders inside this step's closing weight-gradient launches (ops.GeometryPrefetch) instead of at the
+        # head of the next step's forward pass.  step(*batch, next_batch=...) announces the next batch; a batch that was
+        # not announced gets its geometry computed on the spot (correct, not hidden).  coords_of(batch) -> [B,3,N]
+        # channel-first coordinates of a batch (default: the first three channels of batch[0], as both models read).
+        self.prefetch = ops.GeometryPrefetch() if prefetch_geometry else None
+        self.coords_of = coords_of or (lambda batch: batch[0][:, :3])
+        self._announced = None                   # (tensor, version) of the batch whose geometry the buffers hold
+        self._saved_prefetch = ops.set_geometry_prefetch(self.prefetch) if self.prefetch is not None else None
 
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             self._fwd_bwd()                          # discovers the live parameters, builds buckets
+            if self.prefetch is not None:
+                pf = self.prefetch
+                if pf.spec is None or not pf.supported():
+                    ops.set_geometry_prefetch(self._saved_prefetch)          # no chain in this model / unsupported shape
+                    self.prefetch = None
+                else:
+                    pf.allocate(self.static[0].device)
+                    pf.next_xyz.copy_(self.coords_of(self.static).transpose(1, 2))
+                    pf.compute_now(pf.next_xyz)      # geometry of the batch the next (eager) pass sees
             self.reducer.all_reduce()
             self.opt = optimizer if optimizer is not None else FlatAdam(self.reducer, lr, betas, eps, weight_decay)
             self.opt.step()
@@ -179,18 +197,28 @@ class GraphedTrainStep:
         ops.defer_weight_grads(True)          # dW products are queued during backward ...
         try:
             loss.backward()
-            ops.flush_weight_grads()          # ... and issued as one grouped launch
+            # ... and issued as one grouped launch, which also carries the next batch's geometry (prefetch mode)
+            ops.flush_weight_grads(riders=self.prefetch.riders() if self.prefetch is not None else None)
         finally:
             ops.defer_weight_grads(False)
         if self.capture_reduce and self.reducer.buckets is not None:
             self.reducer.all_reduce()         # the remaining buckets + completion of the early ones, inside the graph
         return loss
 
-    def __call__(self, *batch):
+    def __call__(self, *batch, next_batch=None):
         for dst, src in zip(self.static, batch):
             if src is not dst:
                 dst.copy_(src, non_blocking=True)
         self.feeder.refill()
+        if self.prefetch is not None:
+            pf = self.prefetch
+            if self._announced is None or self._announced[0] is not batch[0] or self._announced[1] != batch[0]._version:
+                # this batch was not announced a step ahead: its geometry now, as launches of their own
+                pf.next_xyz.copy_(self.coords_of(batch).transpose(1, 2))
+                pf.compute_now(pf.next_xyz)
+            nxt = next_batch if next_batch is not None else batch      # (no announcement: the same batch again)
+            pf.next_xyz.copy_(self.coords_of(nxt).transpose(1, 2))
+            self._announced = (nxt[0], nxt[0]._version)
         self.graph.replay()
         if is_dist() and world_size() > 1 and not self.capture_reduce:
             if self.reducer.early:                                   # the early bucket(s) first: they are the bulk
@@ -205,3 +233,5 @@ class GraphedTrainStep:
 
     def close(self):
         ops.set_fps_start_hook(None)
+        if self.prefetch is not None:
+            ops.set_geometry_prefetch(self._saved_prefetch)

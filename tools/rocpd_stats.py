@@ -20,8 +20,22 @@ def main():
     top = int(sys.argv[3]) if len(sys.argv) > 3 else 45
     c = sqlite3.connect(db)
     cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
-    name_col = "name" if "name" in cols else "kernel_name"
-    rows = c.execute("select %s, start, end from kernels order by start" % name_col).fetchall()
+    if cols:
+        name_col = "name" if "name" in cols else "kernel_name"
+        rows = c.execute("select %s, start, end from kernels order by start" % name_col).fetchall()
+    else:
+        # no `kernels` view in this database: join the dispatch and symbol tables (rocpd_kernel_dispatch_<guid>,
+        # rocpd_info_kernel_symbol_<guid>) directly
+        tabs = [r[0] for r in c.execute("select name from sqlite_master where type in ('table','view')")]
+        disp = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")]
+        sym = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")]
+        if not disp or not sym:
+            raise SystemExit("no kernel tables in %s: %s" % (db, tabs))
+        dcols = [r[1] for r in c.execute("pragma table_info(%s)" % disp[0])]
+        scols = [r[1] for r in c.execute("pragma table_info(%s)" % sym[0])]
+        nm = "kernel_name" if "kernel_name" in scols else ("display_name" if "display_name" in scols else "name")
+        rows = c.execute("select s.%s, d.start, d.end from %s d join %s s on d.kernel_id = s.id order by d.start"
+                         % (nm, disp[0], sym[0])).fetchall()
     if last:
         idx = [i for i, r in enumerate(rows) if "adam_kernel" in r[0]]
         g = idx[-1]
