@@ -316,7 +316,9 @@ def run_config(name, a, world, rank, dev, steps, warmup, headline):
         # all-reduce them INSIDE the captured graph, overlapped with the rest of backward.  Off by default: RCCL under
         # graph capture has run on one rank only (tests/test_gpu_rccl_capture.py), never across GPUs.
         cap = world > 1 and os.environ.get("MPA_CAPTURE_REDUCE") == "1" and w["split"] is not None
-        prefetch = w["has_chain"] and not cap and os.environ.get("MPA_NO_PREFETCH") is None
+        # MPA_PREFETCH=1: the next batch's sampling chain rides in this step's weight-gradient launches
+        # (ops.GeometryPrefetch).  Off by default: measured 3.83 ms against 3.70 ms per cls-fp32 step.
+        prefetch = w["has_chain"] and not cap and os.environ.get("MPA_PREFETCH") == "1"
         graphed = GraphedTrainStep(model, crit, data, lr=1e-3, compute_loss=w["compute_loss"],
                                    split_after=w["split"] if cap else None, capture_reduce=cap,
                                    prefetch_geometry=prefetch)                                    # optim.FlatAdam

@@ -263,6 +263,8 @@ typedef struct MpaGeoRider {
     int sN, sS, sK;
     float *dist;
     int64_t *kidx;
+    int *queue;     /* 16 ints, ZEROED by the caller before every call that carries the rider (work counters, finished
+                     * sampling workgroups); NULL: the rider is never carried, it goes out as a launch of its own */
 } MpaGeoRider;
 /* mpa_gemm_tn_grouped_f32 with riders: rider i travels in the i-th weight-gradient launch of the call (40 problems per
  * launch), riders beyond the number of launches are issued afterwards as launches of their own, in order -- so a

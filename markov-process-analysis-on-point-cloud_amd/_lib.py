@@ -77,7 +77,7 @@ class GeoRider(ctypes.Structure):
     """struct MpaGeoRider of include/mpa_hip.h"""
     _fields_ = [("src", _vp), ("B", _i), ("N", _i), ("nlev", _i), ("S", _i * 4), ("start", _vp * 4), ("idx", _vp * 4),
                 ("xyz", _vp * 4), ("base", _vp), ("query", _vp), ("sN", _i), ("sS", _i), ("sK", _i), ("dist", _vp),
-                ("kidx", _vp)]
+                ("kidx", _vp), ("queue", _vp)]
 
 
 SIGNATURES["mpa_gemm_tn_grouped_rider_f32"] = [ctypes.POINTER(GemmTnProblem), _i, _vp, ctypes.c_size_t,

@@ -17,6 +17,7 @@
 #define MPA_KNN_BODIES_ONLY
 #endif
 #include "knn.hip"
+#include <cstdlib>
 
 namespace {
 
@@ -34,7 +35,10 @@ struct RiderArgs {
     float *dist;                            // [B][sS][sK]
     int64_t *kidx;
     int sN, sS, sK, qb;
+    int res;                                // search with the base cloud resident in LDS (both passes out of LDS)
     int fps_blocks, blocks;                 // B (or 0); fps_blocks + qb*B
+    int sblocks;                            // qb*B search workgroups (0: none)
+    int *queue;                             // carried riders: word [8] counts finished sampling workgroups (zeroed by the caller)
 };
 
 // one level, width chosen by the number of points it samples FROM (as mpa_fps_f32 does: a single wave up to 512 points)
@@ -58,14 +62,67 @@ __device__ __forceinline__ void rider_level(const float *sx, const float *sy, co
 // (source of levels 1, 3; absent when nlev == 1), then 8 64-bit slots.
 __device__ __forceinline__ int rider_pad4(int n) { return (n + 3) & ~3; }
 
+__device__ __forceinline__ void rider_search(const RiderArgs &r, const int rb, float *lds)
+{
+    if (r.res)
+        knn_mfma_body<3, 4, 8, 1, true, false>(r.base, r.query, r.sN, r.sS, r.sK, r.dist, r.kidx, rb % r.qb, rb / r.qb, lds);
+    else
+        knn_mfma_body<3, 4, 8, 1, false, false>(r.base, r.query, r.sN, r.sS, r.sK, r.dist, r.kidx, rb % r.qb, rb / r.qb, lds);
+}
+
+__device__ __forceinline__ void rider_sample(const RiderArgs &r, const int b, float *lds);
+
 __device__ __forceinline__ void rider_body(const RiderArgs &r, const int bid, float *lds)
 {
-    if (bid >= r.fps_blocks) {
-        const int rb = bid - r.fps_blocks;
-        knn_mfma_body<3, 4, 8, 1, false, false>(r.base, r.query, r.sN, r.sS, r.sK, r.dist, r.kidx, rb % r.qb, rb / r.qb, lds);
+    if (bid >= r.fps_blocks) rider_search(r, bid - r.fps_blocks, lds);
+    else rider_sample(r, bid, lds);
+}
+
+// Where a CARRIED rider's workgroups sit in the carrying launch.  A sampling workgroup that shares its CU with one of
+// the carrier's MFMA workgroups runs 2.3x slower (431 us instead of 186 for the 1024 -> 512 level, measured; raising
+// the sampling waves' priority changes nothing), which stretches the launch instead of hiding in it.  Workgroups b and b + 8 of a grid land on the same XCD (MI355X_MICROARCH.md, workgroup dispatch: observed,
+// speed only), and an XCD holds `slots` = 32 CUs x (workgroups per CU of this kernel) of them at a time -- so the first
+// `slots * nx` ids that are = 0..nx-1 (mod 8) are given to the rider: one per cloud samples, the rest PARK (thread 0
+// sleeps until every sampling workgroup has finished, bounded) so that no carrier workgroup can be placed beside a
+// sampling one.  All other ids are persistent workers that walk the launch's work items with a fixed stride (ids
+// beyond one resident set would queue behind the rider's XCD lanes: the dispatcher places ids in order).  Nothing here
+// is needed for correctness: any placement computes the same results.
+// MEASURED (tools/rider_dw_bench.py, the 59 products of a classification step, 2 launches + reduces = 510 us):
+// sampling riders placed this way 766 us, unplaced (beside MFMA workgroups) 794 us, as launches of their own before
+// the products 845 us -- the lanes reserved for the chain stay idle for the rest of their launch, so carrying the
+// chain saves ~80 us of its 340 us while the two searches it used to hide (64 + 30 us) come out in the open:
+// runtime.GraphedTrainStep(prefetch_geometry=True) is therefore OFF by default.
+struct RiderPlace {
+    int region, nx, slots, per_lane;         // ids [0, region) with (id & 7) < nx are the rider's; the first per_lane
+    int workers;                             // of each lane sample (cloud = lane * per_lane + position), the others park;
+};                                           // workers: ids of the launch that are not the rider's
+
+// -> cloud index (>= 0), -2: park, -1: not a rider id
+__device__ __forceinline__ int rider_slot(const RiderPlace &pl, const int id)
+{
+    if (id >= pl.region || (id & 7) >= pl.nx) return -1;
+    const int pos = id >> 3, lane = id & 7;
+    return pos < pl.per_lane ? lane * pl.per_lane + pos : -2;
+}
+
+__device__ __forceinline__ void rider_sample_or_park(const RiderArgs &r, const int slot, float *lds)
+{
+    if (slot >= 0 && slot < r.fps_blocks) {
+        rider_sample(r, slot, lds);
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(r.queue + 8, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
-    const int b = bid, tid = threadIdx.x;
+    if (threadIdx.x != 0) return;
+    for (int spins = 0; spins < 4000; ++spins) {          // ~1.7 us per turn: gives up after ~7 ms whatever happens
+        if (__hip_atomic_load(r.queue + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= r.fps_blocks) break;
+        __builtin_amdgcn_s_sleep(64);
+    }
+}
+
+__device__ __forceinline__ void rider_sample(const RiderArgs &r, const int b, float *lds)
+{
+    const int tid = threadIdx.x;
     const int strideA = rider_pad4(r.N), strideB = rider_pad4(r.S[0]);
     float *regA = lds, *regB = lds + 3 * strideA;
     unsigned long long *slot = reinterpret_cast<unsigned long long *>(regB + (r.nlev > 1 ? 3 * strideB : 0));
@@ -99,7 +156,7 @@ __global__ __launch_bounds__(256) void geo_rider_kernel(const RiderArgs r)
 }
 
 // host: validate a rider of the C ABI and lay it out for the kernels.  -> MPA_OK / MPA_E*
-inline int rider_prepare(const MpaGeoRider &in, RiderArgs &r, size_t &lds_bytes)
+inline int rider_prepare(const MpaGeoRider &in, RiderArgs &r, size_t &lds_bytes, size_t lds_budget = 64 * 1024)
 {
     if (in.B <= 0 || in.nlev < 0 || in.nlev > RIDER_LEVELS) return MPA_EINVAL;
     r.src = in.src; r.B = in.B; r.N = in.N; r.nlev = in.nlev;
@@ -137,8 +194,18 @@ inline int rider_prepare(const MpaGeoRider &in, RiderArgs &r, size_t &lds_bytes)
         knn_lds = ((size_t)4 * (32 * (4 + 4) + 32) + KNN_G * 32 + 32 + 64 + 2 * 32 * KNN_CAP) * sizeof(float);
         const size_t merge = (size_t)32 * 2 * 4 * 8 * 8;
         if (merge > knn_lds) knn_lds = merge;
+        // the resident form (a C = 3 tile visit out of LDS instead of a global round trip, knn.hip) when the cloud fits
+        // what the carrying launch has anyway
+        const size_t resident = knn_lds + (size_t)mpa_ceil_div(in.sN, 32) * 32 * 5 * sizeof(float);
+        static const bool no_res = getenv("MPA_RIDER_NO_RESIDENT") != nullptr;
+        r.res = (in.sN <= KNN_RES_MAX && resident <= lds_budget && !no_res) ? 1 : 0;
+        if (r.res) knn_lds = resident;
+    } else {
+        r.res = 0;
     }
     r.fps_blocks = in.nlev > 0 ? in.B : 0;
+    r.sblocks = sblocks;
+    r.queue = in.queue;
     r.blocks = r.fps_blocks + sblocks;
     if (r.blocks == 0) return MPA_EINVAL;
     lds_bytes = fps_lds > knn_lds ? fps_lds : knn_lds;

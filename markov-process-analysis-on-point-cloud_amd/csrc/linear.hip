@@ -499,14 +499,46 @@ __global__ __launch_bounds__(NT, 2) void gemm_tn_grouped_kernel(const GroupedArg
 // The same launch carrying a geometry rider (geo_rider.h): its first r.blocks workgroups sample / search the NEXT
 // batch's coordinates -- they are dispatched first and run for the length of the launch on one CU slot per cloud --
 // the others are the weight-gradient products.
-__global__ __launch_bounds__(NT, 2) void gemm_tn_grouped_rider_kernel(const GroupedArgs args, const RiderArgs r)
+// sampling only (no search items): the workers' loop touches nothing of the rider, which keeps its scalar registers
+// out of the tile body (the general kernel below spills 129 of them)
+__global__ __launch_bounds__(NT, 2) void gemm_tn_grouped_fps_kernel(const GroupedArgs args, const RiderArgs r,
+                                                                    const RiderPlace pl, const int gemm_blocks)
 {
     extern __shared__ float lds[];
-    if ((int)blockIdx.x < r.blocks) {
-        rider_body(r, blockIdx.x, lds);
+    const int id = blockIdx.x;
+    if (id < pl.region && (id & 7) < pl.nx) {
+        rider_sample_or_park(r, rider_slot(pl, id), lds);
         return;
     }
-    tn_grouped_block(args, blockIdx.x - r.blocks);
+    const int rank = id < pl.region ? (id >> 3) * (8 - pl.nx) + ((id & 7) - pl.nx) : id - pl.slots * pl.nx;
+    const int stride = pl.workers;
+    for (int item = rank; item < gemm_blocks; item += stride) {
+        tn_grouped_block(args, item);
+        __syncthreads();                          // the next tile reuses this one's LDS
+    }
+}
+
+__global__ __launch_bounds__(NT, 2) void gemm_tn_grouped_rider_kernel(const GroupedArgs args, const RiderArgs r,
+                                                                      const RiderPlace pl, const int gemm_blocks)
+{
+    extern __shared__ float lds[];
+    const int slot = rider_slot(pl, blockIdx.x);
+    if (slot != -1) {
+        rider_sample_or_park(r, slot, lds);          // (see geo_rider.h: the chain gets CUs of its own)
+        return;
+    }
+    // a worker: its rank among the launch's worker ids, then every `workers`-th item from there (workers is a multiple
+    // of 8 and ranks keep id % 8 apart, so a worker -- and with it an XCD -- stays inside one residue class of the items,
+    // which is what the carrier's XCD-aware tile order assumes)
+    const int id = blockIdx.x;
+    const int lanes_free = 8 - pl.nx;
+    const int rank = id < pl.region ? (id >> 3) * lanes_free + ((id & 7) - pl.nx) : id - pl.slots * pl.nx;
+    const int total = r.sblocks + gemm_blocks;
+    for (int item = rank; item < total; item += pl.workers) {
+        if (item < r.sblocks) rider_search(r, item, lds);
+        else tn_grouped_block(args, item - r.sblocks);
+        __syncthreads();                          // the next item reuses this one's LDS
+    }
 }
 
 // ---- grouped forward / dX products: a few INDEPENDENT  C_p = A_p op(B_p) (+ bias)  in one launch -- the Linear units
@@ -1601,7 +1633,11 @@ extern "C" int mpa_gemm_tn_grouped_rider_f32(const MpaGemmTnProblem *problems, i
         }
         ga.count = n;
         ra.count = nr;
-        if (launch_no < nriders) {
+        if (launch_no < nriders && riders[launch_no].queue == nullptr) {
+            const int rc = rider_launch_alone(riders[launch_no], st);         // no queue words: not carried
+            if (rc != MPA_OK) return rc;
+            hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(blocks), dim3(NT), gemm_lds_bytes(true, false), st, ga);
+        } else if (launch_no < nriders) {
             // this launch carries rider `launch_no` (riders are in dependency order: one per launch, in stream order)
             RiderArgs rd;
             size_t rlds = 0;
@@ -1611,10 +1647,43 @@ extern "C" int mpa_gemm_tn_grouped_rider_f32(const MpaGemmTnProblem *problems, i
             if (rlds > lds) {
                 lds = rlds;
                 if (hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tn_grouped_rider_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+                    hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tn_grouped_fps_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
                     return MPA_EHIP;
             }
-            hipLaunchKernelGGL(gemm_tn_grouped_rider_kernel, dim3(blocks + rd.blocks), dim3(NT), lds, st, ga, rd);
+            // 2 workgroups of this kernel per CU (200 registers, >= 64 KiB of LDS): 64 per XCD
+            RiderPlace pl;
+            pl.slots = 64;
+            // sampling workgroups per XCD lane: `MPA_RIDER_PER_LANE` (development) or one per CU (32), the lane's
+            // other ids park
+            static const int per_lane_env = getenv("MPA_RIDER_PER_LANE") ? atoi(getenv("MPA_RIDER_PER_LANE")) : 32;
+            pl.per_lane = per_lane_env < 1 ? 1 : (per_lane_env > pl.slots ? pl.slots : per_lane_env);
+            pl.nx = rd.fps_blocks > 0 ? mpa_ceil_div(rd.fps_blocks, pl.per_lane) : 0;
+            pl.region = 8 * pl.slots;
+            const int work = rd.sblocks + blocks;
+            int grid;
+            if (pl.nx == 0 || pl.nx > 7) {           // no sampling (or more clouds than 7 lanes hold): plain workers
+                pl.nx = 0; pl.region = 0;
+                if (rd.fps_blocks > 0) {
+                    const int rc2 = rider_launch_alone(riders[launch_no], st);
+                    if (rc2 != MPA_OK) return rc2;
+                    rd.sblocks = 0;
+                }
+                grid = rd.sblocks + blocks;
+            } else {
+                // exactly one resident set of workgroups (2 per CU): the rider's on its XCD lanes, persistent workers on
+                // the others, each walking the items with a fixed stride.  (Workgroup ids beyond the resident set would
+                // queue behind the rider's lanes: the dispatcher places ids in order and id % 8 picks the XCD, so the
+                // first id that must wait for a sampling workgroup to leave holds up every id after it -- 758 us per
+                // launch, measured.)
+                grid = pl.region;
+            }
+            pl.workers = grid - pl.slots * pl.nx;
+            if (rd.sblocks == 0 && pl.nx > 0)
+                hipLaunchKernelGGL(gemm_tn_grouped_fps_kernel, dim3(grid), dim3(NT), lds, st, ga, rd, pl, blocks);
+            else
+                hipLaunchKernelGGL(gemm_tn_grouped_rider_kernel, dim3(grid), dim3(NT), lds, st, ga, rd, pl, blocks);
         } else {
             hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(blocks), dim3(NT), gemm_lds_bytes(true, false), st, ga);
         }

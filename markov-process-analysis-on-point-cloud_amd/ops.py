@@ -570,6 +570,9 @@ class GeometryPrefetch:
     def __init__(self):
         self.spec = None             # ((B, N, 3), npoints, k) recorded by the first GeometryChain of a discovery pass
         self.enabled = True
+        # searches carried by the riders (development switch MPA_RIDER_SEARCH=0: sampling only, levels 0 / 1 are
+        # searched inside the forward pass like the deeper levels)
+        self.with_search = os.environ.get("MPA_RIDER_SEARCH", "1") != "0"
         self.ready = False           # buffers hold the geometry of the batch the next forward pass will see
         self.next_xyz = None         # [B, N, 3] coordinates of the next batch (static: captured graphs read it)
         self.fps_idx, self.fps_xyz, self.knn = [], [], []
@@ -598,11 +601,12 @@ class GeometryPrefetch:
         THIS pass will use for the next batch."""
         (B, N, _), npoints, k = self.spec
         g0 = chain.levels[0]
-        g0.dist, g0.idx = self.knn[0]
+        if self.with_search:
+            g0.dist, g0.idx = self.knn[0]
         for i in range(len(npoints)):
             g = _GeoLevel()
             g.xyz, g.fps_idx, g.chain, g.i = self.fps_xyz[i], self.fps_idx[i], chain, i + 1
-            if i == 0 and len(self.knn) > 1:
+            if i == 0 and len(self.knn) > 1 and self.with_search:
                 g.dist, g.idx = self.knn[1]
             chain.levels[i + 1] = g
         self.starts = self._draw_starts(g0.xyz.device)
@@ -613,6 +617,12 @@ class GeometryPrefetch:
             return None
         arr = self._riders(self.next_xyz, self.starts)
         self.starts = None
+        # the carried form's two counters per rider (work queue, finished sampling workgroups): pre-zeroed words of the
+        # pass's arena (inside a captured graph: cleared by the graph's first node at every replay)
+        q = _zeros_acc(32, self.next_xyz.device)
+        for i in range(2):
+            arr[i].queue = q.data_ptr() + 64 * i
+        self._keep = self._keep + (q,)
         return arr
 
     def _riders(self, xyz, starts):
@@ -621,14 +631,16 @@ class GeometryPrefetch:
         r0, r1 = arr[0], arr[1]
         r0.src, r0.B, r0.N, r0.nlev = xyz.data_ptr(), B, N, 1
         r0.S[0], r0.start[0], r0.idx[0], r0.xyz[0] = npoints[0], starts[0].data_ptr(), self.fps_idx[0].data_ptr(), self.fps_xyz[0].data_ptr()
-        r0.base, r0.query, r0.sN, r0.sS, r0.sK = xyz.data_ptr(), xyz.data_ptr(), N, N, k
-        r0.dist, r0.kidx = self.knn[0][0].data_ptr(), self.knn[0][1].data_ptr()
+        if self.with_search:
+            r0.base, r0.query, r0.sN, r0.sS, r0.sK = xyz.data_ptr(), xyz.data_ptr(), N, N, k
+            r0.dist, r0.kidx = self.knn[0][0].data_ptr(), self.knn[0][1].data_ptr()
         r1.src, r1.B, r1.N, r1.nlev = self.fps_xyz[0].data_ptr(), B, npoints[0], len(npoints) - 1
         for j in range(1, len(npoints)):
             r1.S[j - 1], r1.start[j - 1] = npoints[j], starts[j].data_ptr()
             r1.idx[j - 1], r1.xyz[j - 1] = self.fps_idx[j].data_ptr(), self.fps_xyz[j].data_ptr()
-        r1.base, r1.query, r1.sN, r1.sS, r1.sK = xyz.data_ptr(), self.fps_xyz[0].data_ptr(), N, npoints[0], k
-        r1.dist, r1.kidx = self.knn[1][0].data_ptr(), self.knn[1][1].data_ptr()
+        if self.with_search:
+            r1.base, r1.query, r1.sN, r1.sS, r1.sK = xyz.data_ptr(), self.fps_xyz[0].data_ptr(), N, npoints[0], k
+            r1.dist, r1.kidx = self.knn[1][0].data_ptr(), self.knn[1][1].data_ptr()
         self._keep = (xyz, starts)       # (the launches are asynchronous: keep their operands alive)
         return arr
 
