@@ -372,6 +372,28 @@ int mpa_three_interp_fwd_bf16(const mpa_bf16 *points2, const int64_t *idx, const
 int mpa_three_interp_bwd_bf16(const mpa_bf16 *grad_out, const int64_t *idx, const float *dist,
                               int B, int Nq, int Nb, int C, float *grad_points2, void *stream);
 
+/* ---- the tails of the models' heads, one launch each way (csrc/head.hip).
+ * log_softmax over the class axis of x [M,C] (models/repsurf/repsurf_ssg_umb.py:67) and its backward
+ * grad_x = grad_y - exp(y) * sum_c grad_y. */
+int mpa_log_softmax_fwd_f32(const float *x, int M, int C, float *y, void *stream);
+int mpa_log_softmax_bwd_f32(const float *y, const float *grad_y, int M, int C, float *grad_x, void *stream);
+/* Label-smoothed loss, mean over the M rows of -sum_c w_c lp_c with w = 1-eps at the target class and eps/(C-1)
+ * elsewhere: from_logits = 0: x are log-probabilities (SmoothClsLoss, util/utils.py:74-88); from_logits = 1: x are
+ * logits, lp = log_softmax(x) (get_loss, models/repsurf/pointnet2_part_seg_msg.py:159-180; lse [M] receives the rows'
+ * log-sum-exp for the backward).  partial: mpa_smooth_loss_workspace_floats(M) floats of scratch (per-block sums,
+ * combined in a fixed order: the loss is bit-reproducible).  loss [1].  Backward: grad_x [M,C] = grad_loss[0] *
+ * d loss / d x. */
+int mpa_smooth_loss_workspace_floats(int M);
+int mpa_smooth_loss_fwd_f32(const float *x, const int64_t *target, int M, int C, float eps, int from_logits,
+                            float *lse, float *partial, float *loss, void *stream);
+int mpa_smooth_loss_bwd_f32(const float *x, const int64_t *target, const float *lse, const float *grad_loss,
+                            int M, int C, float eps, int from_logits, float *grad_x, void *stream);
+/* cat(max over the P points, mean over the P points) of x [B,P,C] -> out [B,2C] (the classification head's pooling,
+ * modules/repsurface_utils.py:629-633); arg [B,C] = first row attaining the maximum (a NaN is kept, as torch.max).
+ * Backward: grad_x [B,P,C] fully written. */
+int mpa_pool_max_mean_fwd_f32(const float *x, int B, int P, int C, float *out, int *arg, void *stream);
+int mpa_pool_max_mean_bwd_f32(const float *grad_out, const int *arg, int B, int P, int C, float *grad_x, void *stream);
+
 /* ---- optimizer step over flat buckets (the training loop of tool/train_cls_scanobjectnn.py:205-216
  * uses torch.optim.Adam; gradients here live in a few flat buffers, so one elementwise pass per
  * bucket replaces ~300 per-parameter launches).  torch.optim.Adam arithmetic, no amsgrad.

@@ -141,6 +141,16 @@ SIGNATURES.update({
     "mpa_three_interp_bwd_bf16": SIGNATURES["mpa_three_interp_bwd_f32"],
 })
 
+SIGNATURES.update({
+    "mpa_log_softmax_fwd_f32": [_vp, _i, _i, _vp, _vp],
+    "mpa_log_softmax_bwd_f32": [_vp, _vp, _i, _i, _vp, _vp],
+    "mpa_smooth_loss_workspace_floats": [_i],
+    "mpa_smooth_loss_fwd_f32": [_vp, _vp, _i, _i, _f, _i, _vp, _vp, _vp, _vp],
+    "mpa_smooth_loss_bwd_f32": [_vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp, _vp],
+    "mpa_pool_max_mean_fwd_f32": [_vp, _i, _i, _i, _vp, _vp, _vp],
+    "mpa_pool_max_mean_bwd_f32": [_vp, _vp, _i, _i, _i, _vp, _vp],
+})
+
 for _name, _args in SIGNATURES.items():
     _fn = getattr(lib, _name)
     _fn.argtypes = _args

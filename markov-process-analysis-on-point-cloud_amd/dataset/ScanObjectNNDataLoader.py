@@ -1,38 +1,43 @@
-"""ScanObjectNN reader -- mirror of the reference's dataset/ScanObjectNNDataLoader.py:9-31
-(`<root>/main_split[_nobg]/{training,test}_objectdataset_augmentedrot_scale75.h5`, arrays `data`
-[n, 2048, 3] and `label` [n]).  Needs h5py, which is imported when the class is constructed: the
-build image of this project does not have it, so there this reader raises ImportError with that
-message instead of failing at package import ("parity unpinned": no h5 file or h5py to test with)."""
-import warnings
+"""ScanObjectNN reader with the reference's interface (dataset/ScanObjectNNDataLoader.py:9-31): constructor
+`(root, split='training', bg=True)`, items `(cloud [3, N] float32 channel-first, label int64)`.
+
+On-disk contract (the dataset's published layout): `<root>/main_split/` (objects with background points) or
+`<root>/main_split_nobg/`, one HDF5 file per split named `<split>_objectdataset_augmentedrot_scale75.h5` holding
+`data` [n, 2048, 3] and `label` [n].  h5py is imported on construction, not at package import: the image this
+project is built in has no h5py and no ScanObjectNN file, so this reader is untested here ("parity unpinned")."""
+import os
 
 from torch.utils.data import Dataset
 
-warnings.filterwarnings('ignore')
+_SPLITS = ("training", "test")
+_H5_SUFFIX = "_objectdataset_augmentedrot_scale75.h5"
+
+
+def _h5py():
+    try:
+        import h5py
+    except ImportError as e:
+        raise ImportError("ScanObjectNNDataLoader reads HDF5 files and needs h5py, which is not installed") from e
+    return h5py
 
 
 class ScanObjectNNDataLoader(Dataset):
     def __init__(self, root, split='training', bg=True):
-        try:
-            import h5py
-        except ImportError as e:
-            raise ImportError("ScanObjectNNDataLoader reads HDF5 files and needs h5py, which is not installed") from e
-        self.root = root
-        assert (split == 'training' or split == 'test')
-        if bg:
-            print('Use data with background points')
-            dir_name = 'main_split'
-        else:
-            print('Use data without background points')
-            dir_name = 'main_split_nobg'
-        h5_name = '{}/{}/{}'.format(self.root, dir_name, split + '_objectdataset_augmentedrot_scale75.h5')
-        with h5py.File(h5_name, mode="r") as f:
-            self.data = f['data'][:].astype('float32')
-            self.label = f['label'][:].astype('int64')
-        print('The size of %s data is %d' % (split, self.data.shape[0]))
+        h5py = _h5py()
+        if split not in _SPLITS:
+            raise ValueError("split must be one of %s, got %r" % (_SPLITS, split))
+        self.root, self.split, self.bg = root, split, bool(bg)
+        self.path = os.path.join(root, "main_split" if bg else "main_split_nobg", split + _H5_SUFFIX)
+        with h5py.File(self.path, mode="r") as f:
+            # whole arrays in host memory, converted once: clouds stay [n, N, 3] and are transposed per item
+            self.data = f["data"][:].astype("float32")
+            self.label = f["label"][:].astype("int64")
 
     def __len__(self):
-        return self.data.shape[0]
+        return len(self.label)
 
     def __getitem__(self, index):
-        """channel-first cloud [3, N], label"""
         return self.data[index].T, self.label[index]
+
+    def __repr__(self):
+        return "ScanObjectNNDataLoader(%s, %d clouds, %s background)" % (self.split, len(self), "with" if self.bg else "without")

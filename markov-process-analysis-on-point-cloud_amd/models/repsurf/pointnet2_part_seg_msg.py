@@ -36,15 +36,5 @@ class get_loss(nn.Module):
     """Label-smoothed cross entropy on logits (reference :159-180)."""
 
     def forward(self, pred, target, trans_feat=None):
-        target = target.contiguous().view(-1)
-        eps = 0.1
-        n_class = pred.size(1)
-        one_hot = pred.new_zeros(pred.shape).scatter(1, target.view(-1, 1), 1)
-        one_hot = one_hot * (1 - eps) + (1 - one_hot) * eps / (n_class - 1)
-        per_point = -(one_hot * F.log_softmax(pred, dim=1)).sum(dim=1)
-        n = per_point.numel()
-        if n > 4096 and n % 64 == 0:
-            # mean in two stages (<= 64 and n/64 elements): keeps torch off its multi-workgroup
-            # reduction, whose result is not reliable under HIP-graph replay (see _max_over_points)
-            return per_point.view(-1, 64).mean(dim=1).mean()
-        return per_point.mean()
+        # -(smoothed one-hot * log_softmax(pred, 1)).sum(1).mean() with eps = 0.1, as one op (logits in, fixed-order mean)
+        return ops.smooth_loss(pred, target.contiguous().view(-1), 0.1, from_logits=True)

@@ -30,7 +30,7 @@ class Model(nn.Module):
         x = self.keepHigh(center, normal)
         x = self.drop1(ops.linear_bn_act(x, self.fc1.weight, self.fc1.bias, self.bn1, 0.2))
         x = self.drop2(ops.linear_bn_act(x, self.fc2.weight, self.fc2.bias, self.bn2, 0.2))
-        return F.log_softmax(ops.linear(x, self.fc3.weight, self.fc3.bias, out_dtype=torch.float32), -1)
+        return ops.log_softmax(ops.linear(x, self.fc3.weight, self.fc3.bias, out_dtype=torch.float32))
 
 
 class SmoothClsLoss(nn.Module):
@@ -41,8 +41,5 @@ class SmoothClsLoss(nn.Module):
         self.smoothing_ratio = smoothing_ratio
 
     def forward(self, pred, target):
-        eps = self.smoothing_ratio
-        n_class = pred.size(1)
-        one_hot = pred.new_zeros(pred.shape).scatter(1, target.view(-1, 1), 1)
-        one_hot = one_hot * (1 - eps) + (1 - one_hot) * eps / (n_class - 1)
-        return -(one_hot * pred).sum(dim=1).mean()
+        # -(one_hot * (1 - eps) + (1 - one_hot) * eps / (n_class - 1) * pred).sum(1).mean() as one op
+        return ops.smooth_loss(pred, target, self.smoothing_ratio, from_logits=False)

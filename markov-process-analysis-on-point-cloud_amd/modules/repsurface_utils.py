@@ -231,5 +231,5 @@ class KeepHighResolutionModule(nn.Module):
                                     geometry=g)
             base = g.xyz
         final = self.conv4(self.conv3(feat))                       # [B,32,1024]
-        fused = torch.cat((final.max(dim=1)[0], final.mean(dim=1)), 1)     # (32 points per output: one workgroup each)
+        fused = ops.pool_max_mean(final)                            # cat((final.max(dim=1)[0], final.mean(dim=1)), 1)
         return ops.linear_bn_act(fused, self.final_class.weight, self.final_class.bias, self.bn, 0.2)

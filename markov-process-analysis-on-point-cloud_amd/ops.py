@@ -1014,6 +1014,93 @@ def max_over_points(x):
     return _MaxOverPoints.apply(_feat(x))
 
 
+# ------------------------------------------------------------------------------- heads: log-softmax, losses, pooling
+class _LogSoftmax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        M, C = x.shape
+        y = torch.empty_like(x)
+        _launch("mpa_log_softmax_fwd_f32", _p(x), M, C, _p(y), _stream())
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        M, C = y.shape
+        gx = torch.empty_like(y)
+        _launch("mpa_log_softmax_bwd_f32", _p(y), _p(g.contiguous()), M, C, _p(gx), _stream())
+        return gx
+
+
+def log_softmax(x):
+    """F.log_softmax(x, -1) for fp32 logits [..., C] (models/repsurf/repsurf_ssg_umb.py:67): one launch each way."""
+    _dev(x)
+    lead = x.shape[:-1]
+    return _LogSoftmax.apply(_f32(x).reshape(-1, x.shape[-1])).view(*lead, x.shape[-1])
+
+
+class _SmoothLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, target, eps, from_logits):
+        M, C = x.shape
+        loss = torch.empty(1, dtype=torch.float32, device=x.device)
+        lse = torch.empty(M, dtype=torch.float32, device=x.device) if from_logits else None
+        part = torch.empty(int(lib.mpa_smooth_loss_workspace_floats(M)), dtype=torch.float32, device=x.device)
+        _launch("mpa_smooth_loss_fwd_f32", _p(x), _p(target), M, C, float(eps), int(from_logits), _p(lse), _p(part), _p(loss),
+                _stream())
+        ctx.save_for_backward(x, target, lse)
+        ctx.cfg = (float(eps), int(from_logits))
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        x, target, lse = ctx.saved_tensors
+        eps, from_logits = ctx.cfg
+        M, C = x.shape
+        gx = torch.empty_like(x)
+        _launch("mpa_smooth_loss_bwd_f32", _p(x), _p(target), _p(lse), _p(g.contiguous().view(1)), M, C, eps, from_logits,
+                _p(gx), _stream())
+        return gx, None, None, None
+
+
+def smooth_loss(x, target, eps=0.1, from_logits=False):
+    """Label-smoothed loss over rows x [M,C] with int64 targets [M]: the mean of -sum_c w_c lp_c, w = 1-eps at the target
+    and eps/(C-1) elsewhere.  from_logits=False: x are log-probabilities (reference util/utils.py:74-88); True: x are
+    logits and lp = log_softmax(x) (models/repsurf/pointnet2_part_seg_msg.py:159-180).  Two launches forward (rows, then
+    a fixed-order sum: bit-reproducible), one backward -- the reference's formulation is ~15 elementwise launches."""
+    _dev(x, target)
+    return _SmoothLoss.apply(_f32(x), _i64(target).view(-1), eps, bool(from_logits))
+
+
+class _PoolMaxMean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        B, P, C = x.shape
+        out = torch.empty(B, 2 * C, dtype=torch.float32, device=x.device)
+        arg = torch.empty(B, C, dtype=torch.int32, device=x.device)
+        _launch("mpa_pool_max_mean_fwd_f32", _p(x), B, P, C, _p(out), _p(arg), _stream())
+        ctx.save_for_backward(arg)
+        ctx.dims = (B, P, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (arg,) = ctx.saved_tensors
+        B, P, C = ctx.dims
+        gx = torch.empty(B, P, C, dtype=torch.float32, device=g.device)
+        _launch("mpa_pool_max_mean_bwd_f32", _p(g.contiguous()), _p(arg), B, P, C, _p(gx), _stream())
+        return gx
+
+
+def pool_max_mean(x):
+    """torch.cat((x.max(dim=1)[0], x.mean(dim=1)), 1) for x [B,P,C] (the classification head's pooling over the
+    points of the last state, reference modules/repsurface_utils.py:629-633): one launch each way; fp32 (bf16 rows
+    are promoted: the result feeds the per-cloud layers, which run in fp32 anyway)."""
+    _dev(x)
+    return _PoolMaxMean.apply(_f32(_feat(x).float()))
+
+
 class _CatBroadcast(torch.autograd.Function):
     """cat((a [B,N,Ca], rows [B,1,Cr] broadcast over N), 2): per-point features next to per-cloud rows (the
     part-seg head: conv5(points) | global maxima | label embedding, reference modules/pointnet2_utils.py:846-856).

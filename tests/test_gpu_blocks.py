@@ -283,6 +283,17 @@ class _ForcedKnn:
             return fidx, fxyz, rx, rf
         return f
 
+    def fused3(self, real):
+        """wrapper for ops.knn_xyz_and_feature (a state's coordinate and feature searches in one launch, no sampling):
+        both forced, xyz first; when the op fell back to the wrapped knn_point the forcing has happened inside."""
+        def f(k_xyz, xyz_base, xyz_query, k_feat, feat_base, feat_query):
+            before = self.i
+            rx, rf = real(k_xyz, xyz_base, xyz_query, k_feat, feat_base, feat_query)
+            if self.i == before:
+                rx, rf = self.force(*rx), self.force(*rf)
+            return rx, rf
+        return f
+
     def force(self, dist, idx):
         # the reference's recorded call with this shape that has not been used yet (the geometry
         # pass issues all xyz-space kNNs first; per shape the reference's order is xyz, feature)
@@ -301,18 +312,19 @@ def _run_model(g, model, run, patch_mods, prefix):
     patch_mods = list(patch_mods) + [_ops]          # geometry_pass calls ops.knn_point directly
     forced = _ForcedKnn(_ops.knn_point, rec)
     saved = [m.knn_point for m in patch_mods]
-    saved_fused, saved_fused2 = _ops.fps_and_knn_xyz, _ops.fps_knn_fused
+    saved_fused, saved_fused2, saved_fused3 = _ops.fps_and_knn_xyz, _ops.fps_knn_fused, _ops.knn_xyz_and_feature
     for m in patch_mods:
         m.knn_point = forced
     _ops.fps_and_knn_xyz = forced.fused(saved_fused)
     _ops.fps_knn_fused = forced.fused2(saved_fused2)
+    _ops.knn_xyz_and_feature = forced.fused3(saved_fused3)
     try:
         torch.manual_seed(2024)
         out = run(model)
     finally:
         for m, s in zip(patch_mods, saved):
             m.knn_point = s
-        _ops.fps_and_knn_xyz, _ops.fps_knn_fused = saved_fused, saved_fused2
+        _ops.fps_and_knn_xyz, _ops.fps_knn_fused, _ops.knn_xyz_and_feature = saved_fused, saved_fused2, saved_fused3
     assert forced.i == len(rec)
     return out, forced
 
