@@ -242,6 +242,17 @@ typedef struct MpaGemmTnProblem {
 } MpaGemmTnProblem;
 int mpa_gemm_tn_grouped_f32(const MpaGemmTnProblem *problems, int count, float *workspace,
                             size_t workspace_bytes, void *stream);
+/* A COARSE state's geometry step in one launch (csrc/knn_fused.hip): the sampling of the next state (optional:
+ * fps_xyz != NULL; fps_S from fps_N <= 128 points), the coordinate search (optional: xyz_base != NULL; xN <= 256) and
+ * the feature-space search (N <= 256 base rows of C in {32,64,128,256} floats, 16-byte aligned), all K <= 8 -- the
+ * last states of a chain (128 -> 64 -> 32 points in the classification model), where every launch of the general
+ * kernels is latency.  Same outputs, bit for bit, as mpa_fps_f32 + mpa_knn_f32 x 2.  MPA_EUNSUPPORTED outside these
+ * shapes. */
+int mpa_coarse_level_f32(const float *fps_xyz, int B, int fps_N, int fps_S, const int64_t *start_idx,
+                         int64_t *fps_idx, float *fps_out_xyz, const float *xyz_base, const float *xyz_query,
+                         int xN, int xS, int xK, float *xyz_dist, int64_t *xyz_idx, const float *feat_base,
+                         const float *feat_query, int N, int S, int C, int K, float *out_dist, int64_t *out_idx,
+                         void *stream);
 /* Geometry rider: sampling levels and one coordinate search of the NEXT batch, carried by the first workgroups of a
  * long launch of the current step (cross-step co-scheduling of the FPS chain, which depends on coordinates only:
  * modules/repsurface_utils.py:581-619, modules/pointnet2_utils.py:84-109, :211-222).

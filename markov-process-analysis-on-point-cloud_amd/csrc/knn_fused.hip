@@ -5,6 +5,7 @@
 // Workgroups [0, B): fps_body; then the coordinate search's; then the feature search's (bodies of knn.hip).
 #define MPA_KNN_BODIES_ONLY
 #include "knn.hip"
+#include "fps_body.h"
 
 namespace {
 
@@ -79,7 +80,238 @@ int launch_fused_p(int P, const float *fxyz, int B, int fN, int fS, const int64_
     }
 }
 
+// ================================================================================= the coarse states
+// The last states of a chain are a few dozen to a few hundred points: 128 -> 64 -> 32 in the classification model.
+// There every launch of the general kernels is latency -- one or two workgroups per cloud walking 32-row tiles with
+// 4-8 dependent global round trips each (C = 256: 50 us at 1.3 % matrix-pipe utilisation, C = 128: 32 us, C = 64:
+// 29 us), a sampling launch of 8-15 us and a coordinate search of 12-15 us per state, 8 launches and 174 us for the
+// three coarsest states of a classification step.  Here a state's whole geometry step is ONE launch of small
+// workgroups: [0, B) sample the next state (one wave, cloud in registers), the next qx*B search coordinates, the rest
+// search features -- and a search workgroup stages its cloud's WHOLE base (N <= 256 rows) with every load issued
+// before the first use, computes all 32 x N distances in one pass (one or two 32-row tiles per wave, the same MFMA
+// chain and rounding as knn_mfma_body: bit-identical distances), and selects by K rounds of a 64-bit (distance, index)
+// minimum over 8 lanes per query.
+constexpr int SMALL_MAX_N = 256;
+
+template <int CT>
+constexpr size_t small_lds_bytes(int N)
+{
+    const int NP = (N + 31) / 32 * 32;
+    return ((size_t)(NP + 32) * (((CT + 3) & ~3) + 4) + NP + 32 * (size_t)(NP + 1)) * sizeof(float);
+}
+
+template <int CT>
+__device__ __forceinline__ void knn_small_body(const float *__restrict__ base, const float *__restrict__ query, int N,
+                                               int S, int K, float *__restrict__ out_dist, int64_t *__restrict__ out_idx,
+                                               const int bx, const int b, float *lds)
+{
+    constexpr int CP = (CT + 3) & ~3, PITCH = CP + 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int ntiles = (N + 31) / 32, NP = ntiles * 32;
+    float *rows = lds;                               // [NP][PITCH] base rows
+    float *qrows = rows + (size_t)NP * PITCH;        // [32][PITCH] this workgroup's queries
+    float *snorm = qrows + 32 * PITCH;               // [NP]
+    float *dmat = snorm + NP;                        // [32][NP + 1]
+    const float *bp = base + (size_t)b * N * CT;
+    const int q0 = bx * 32;
+    if constexpr (CT == 3) {
+        for (int i = tid; i < NP * 4; i += 256) {
+            const int r = i >> 2, c = i & 3;
+            rows[r * PITCH + c] = (r < N && c < 3) ? bp[r * 3 + c] : 0.f;
+        }
+    } else {
+        constexpr int V = CT / 4;                    // float4 per row
+        const float4 *src = reinterpret_cast<const float4 *>(bp);
+        const int live = N * V, all = NP * V;
+        for (int i0 = tid; i0 < all; i0 += 256 * 8) {
+            float4 tmp[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + 256 * u;
+                tmp[u] = i < live ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + 256 * u;
+                if (i < all) {
+                    const int r = i / V, c4 = i - r * V;
+                    *reinterpret_cast<float4 *>(rows + (size_t)r * PITCH + 4 * c4) = tmp[u];
+                }
+            }
+        }
+    }
+    // the 32 query rows next to them (rows past S repeat the last one; their results are not stored): the MFMA's
+    // query operand q[j][2kk + half] is then one 16-byte LDS read per two products, like the base operand, instead of
+    // CT/2 registers per lane
+    if constexpr (CT == 3) {
+        for (int i = tid; i < 32 * 4; i += 256) {
+            const int r = i >> 2, c = i & 3;
+            qrows[r * PITCH + c] = c < 3 ? query[((size_t)b * S + min(q0 + r, S - 1)) * 3 + c] : 0.f;
+        }
+    } else {
+        constexpr int V = CT / 4;
+        for (int i = tid; i < 32 * V; i += 256) {
+            const int r = i / V, c4 = i - r * V;
+            *reinterpret_cast<float4 *>(qrows + (size_t)r * PITCH + 4 * c4) =
+                reinterpret_cast<const float4 *>(query + ((size_t)b * S + min(q0 + r, S - 1)) * CT)[c4];
+        }
+    }
+    __syncthreads();
+    for (int r = tid; r < NP; r += 256) snorm[r] = r < N ? tile_row_norm<CT>(rows + (size_t)r * PITCH) : INFINITY;
+    const float *qrow = qrows + (size_t)l31 * PITCH;
+    const float qn = tile_row_norm<CT>(qrow);          // |q|^2 by the A2 model (same order as sum_sq_model)
+    __syncthreads();
+    for (int t = wave; t < ntiles; t += 4) {
+        const float *row = rows + (size_t)(t * 32 + l31) * PITCH;
+        float4 sn[4];
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) sn[q4] = *reinterpret_cast<const float4 *>(snorm + t * 32 + 8 * q4 + 4 * half);
+        floatx16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int m = 0; m < CP / 4; ++m) {
+            const float4 a = *reinterpret_cast<const float4 *>(row + 4 * m);
+            const float4 qq = *reinterpret_cast<const float4 *>(qrow + 4 * m);
+            const float a0 = half ? a.y : a.x, a1 = half ? a.w : a.z;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, half ? qq.y : qq.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, half ? qq.w : qq.z, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float d = (-2.0f * acc[r] + qn) + (&sn[r >> 2].x)[r & 3];
+            dmat[l31 * (NP + 1) + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] = d;
+        }
+    }
+    __syncthreads();
+    // selection: 8 lanes per query, lane e owns the candidates n = e + 8 j; K rounds of a 64-bit key minimum
+    // (monotone distance key << 32 | n: smaller distance first, lower index among equals -- the (distance, index) rank)
+    const int q = tid >> 3, e = tid & 7;
+    unsigned long long key[SMALL_MAX_N / 8];
+#pragma unroll
+    for (int j = 0; j < SMALL_MAX_N / 8; ++j) {
+        const int n = e + 8 * j;
+        key[j] = n < N ? ((unsigned long long)((unsigned)f2key(dmat[q * (NP + 1) + n]) ^ 0x80000000u) << 32) | (unsigned)n
+                       : ~0ull;
+    }
+    const bool live = q0 + q < S;
+    const size_t o = ((size_t)b * S + min(q0 + q, S - 1)) * K;
+    for (int k = 0; k < K; ++k) {
+        unsigned long long m = key[0];
+#pragma unroll
+        for (int j = 1; j < SMALL_MAX_N / 8; ++j) m = key[j] < m ? key[j] : m;
+        unsigned long long w = m;
+#pragma unroll
+        for (int sh = 1; sh < 8; sh <<= 1) {
+            const unsigned long long other = __shfl_xor(w, sh, 64);
+            w = other < w ? other : w;
+        }
+        if (m == w && w != ~0ull) {                    // this lane owns the winner: retire it
+#pragma unroll
+            for (int j = 0; j < SMALL_MAX_N / 8; ++j)
+                if (key[j] == w) key[j] = ~0ull;
+        }
+        if (e == 0 && live && w != ~0ull) {
+            const int kb = (int)((unsigned)(w >> 32) ^ 0x80000000u);
+            out_idx[o + k] = (int64_t)(unsigned)(w & 0xffffffffu);
+            if (out_dist) out_dist[o + k] = __int_as_float(kb >= 0 ? kb : kb ^ 0x7fffffff);
+        }
+    }
+}
+
+struct SmallSearch {
+    const float *base, *query;
+    float *dist;
+    int64_t *idx;
+    int N, S, K, qb, blocks;
+};
+
+template <int CT>
+__global__ __launch_bounds__(256) void coarse_level_kernel(const float *__restrict__ fxyz, int fN, int fS,
+                                                           const int64_t *__restrict__ start, int64_t *__restrict__ f_idx,
+                                                           float *__restrict__ f_out_xyz, int fB, SmallSearch x, SmallSearch y)
+{
+    extern __shared__ float lds[];
+    int bid = blockIdx.x;
+    if (bid < fB) {
+        // one wave samples (the cloud in registers, no barrier inside the loop); the others leave
+        float *sx = lds, *sy = lds + 128, *sz = lds + 256;
+        const float *cloud = fxyz + (size_t)bid * fN * 3;
+        for (int i = threadIdx.x; i < fN * 3; i += 256) {
+            const int n = i / 3;
+            lds[(i - 3 * n) * 128 + n] = cloud[i];
+        }
+        __syncthreads();
+        if (threadIdx.x >= 64) return;
+        int64_t *oi = f_idx + (size_t)bid * fS;
+        float *ox = f_out_xyz + (size_t)bid * fS * 3;
+        if (fN <= 64) fps_level<1, 1>(sx, sy, sz, fN, fS, (int)start[bid], oi, ox, nullptr, nullptr, nullptr, nullptr);
+        else fps_level<1, 2>(sx, sy, sz, fN, fS, (int)start[bid], oi, ox, nullptr, nullptr, nullptr, nullptr);
+        return;
+    }
+    bid -= fB;
+    if (bid < x.blocks) {
+        knn_small_body<3>(x.base, x.query, x.N, x.S, x.K, x.dist, x.idx, bid % x.qb, bid / x.qb, lds);
+        return;
+    }
+    bid -= x.blocks;
+    knn_small_body<CT>(y.base, y.query, y.N, y.S, y.K, y.dist, y.idx, bid % y.qb, bid / y.qb, lds);
+}
+
+template <int CT>
+int launch_coarse(const float *fxyz, int fB, int fN, int fS, const int64_t *start, int64_t *f_idx, float *f_out_xyz,
+                  const SmallSearch &x, const SmallSearch &y, hipStream_t st)
+{
+    size_t lds = small_lds_bytes<CT>(y.N);
+    if (x.blocks > 0 && small_lds_bytes<3>(x.N) > lds) lds = small_lds_bytes<3>(x.N);
+    if (lds < 3 * 128 * sizeof(float)) lds = 3 * 128 * sizeof(float);
+    if (lds > 160 * 1024) return MPA_EUNSUPPORTED;
+    if (lds > 64 * 1024) {
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&coarse_level_kernel<CT>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (attr != hipSuccess) return MPA_EHIP;
+    }
+    hipLaunchKernelGGL((coarse_level_kernel<CT>), dim3(fB + x.blocks + y.blocks), dim3(256), lds, st, fxyz, fN, fS, start,
+                       f_idx, f_out_xyz, fB, x, y);
+    MPA_LAUNCH_CHECK();
+    return MPA_OK;
+}
+
 }  // namespace
+
+// A coarse state's geometry step in one launch (see above): optional sampling of fps_S from fps_N <= 128 points,
+// optional coordinate search (xN <= 256), feature search with N <= 256 rows of C in {32, 64, 128, 256} floats, K <= 8.
+// MPA_EUNSUPPORTED outside those shapes.  Results are bit-identical to mpa_fps_f32 / mpa_knn_f32.
+extern "C" int mpa_coarse_level_f32(const float *fps_xyz, int B, int fps_N, int fps_S, const int64_t *start_idx,
+                                    int64_t *fps_idx, float *fps_out_xyz, const float *xyz_base, const float *xyz_query,
+                                    int xN, int xS, int xK, float *xyz_dist, int64_t *xyz_idx, const float *feat_base,
+                                    const float *feat_query, int N, int S, int C, int K, float *out_dist,
+                                    int64_t *out_idx, void *stream)
+{
+    MPA_CLEAR_ERROR();
+    const bool sample = fps_xyz != nullptr;
+    if (!feat_base || !feat_query || !out_idx || B <= 0 || N <= 0 || S <= 0 || K <= 0) return MPA_EINVAL;
+    if (sample && (!start_idx || !fps_idx || !fps_out_xyz || fps_N <= 0 || fps_S <= 0)) return MPA_EINVAL;
+    if (xyz_base && (!xyz_query || !xyz_idx || xN <= 0 || xS <= 0 || xK <= 0)) return MPA_EINVAL;
+    if (K > 8 || K > N || N > SMALL_MAX_N || (xyz_base && (xK > 8 || xK > xN || xN > SMALL_MAX_N)) ||
+        (sample && fps_N > 128) || (((uintptr_t)feat_base | (uintptr_t)feat_query) & 15) != 0)
+        return MPA_EUNSUPPORTED;
+    SmallSearch x, y;
+    x.base = xyz_base; x.query = xyz_query; x.dist = xyz_dist; x.idx = xyz_idx; x.N = xN; x.S = xS; x.K = xK;
+    x.qb = xyz_base ? mpa_ceil_div(xS, 32) : 1; x.blocks = xyz_base ? x.qb * B : 0;
+    y.base = feat_base; y.query = feat_query; y.dist = out_dist; y.idx = out_idx; y.N = N; y.S = S; y.K = K;
+    y.qb = mpa_ceil_div(S, 32); y.blocks = y.qb * B;
+    hipStream_t st = (hipStream_t)stream;
+    const int fB = sample ? B : 0;
+    switch (C) {
+    case 32: return launch_coarse<32>(fps_xyz, fB, fps_N, fps_S, start_idx, fps_idx, fps_out_xyz, x, y, st);
+    case 64: return launch_coarse<64>(fps_xyz, fB, fps_N, fps_S, start_idx, fps_idx, fps_out_xyz, x, y, st);
+    case 128: return launch_coarse<128>(fps_xyz, fB, fps_N, fps_S, start_idx, fps_idx, fps_out_xyz, x, y, st);
+    case 256: return launch_coarse<256>(fps_xyz, fB, fps_N, fps_S, start_idx, fps_idx, fps_out_xyz, x, y, st);
+    default: return MPA_EUNSUPPORTED;
+    }
+}
 
 extern "C" int mpa_fps_knn_feat_f32(const float *fps_xyz, int B, int fps_N, int fps_S, const int64_t *start_idx,
                                     int64_t *fps_idx, float *fps_out_xyz, const float *xyz_base,

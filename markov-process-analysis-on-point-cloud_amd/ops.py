@@ -405,6 +405,42 @@ def set_fps_feature_fusion(on):
     return old
 
 
+def _coarse_ok(fN, xN, N, C, k_xyz, k_feat, fb, fq):
+    """shapes of mpa_coarse_level_f32 (a coarse state's sampling + searches as one launch of small workgroups)"""
+    return (FUSE_FPS_FEATURE_SEARCH and C in (32, 64, 128, 256) and N <= 256 and (fN is None or fN <= 128)
+            and (xN is None or xN <= 256) and k_feat <= min(8, N) and (k_xyz is None or k_xyz <= 8)
+            and fb.data_ptr() % 16 == 0 and fq.data_ptr() % 16 == 0)
+
+
+def _coarse_level(fps_in, npoint, start_idx, k_xyz, xyz_base, xyz_query, k_feat, fb, fq):
+    B, N, C = fb.shape
+    S = fq.shape[1]
+    dev = fb.device
+    fin = start = fidx = fxyz = None
+    fN = 0
+    if fps_in is not None:
+        fin = _f32(fps_in.detach())
+        fN = fin.shape[1]
+        start = _fps_start(B, fN, dev, start_idx)
+        fidx = torch.empty(B, npoint, dtype=torch.int64, device=dev)
+        fxyz = torch.empty(B, npoint, 3, dtype=torch.float32, device=dev)
+    xb = xq = dx = ix = None
+    xN = xS = 0
+    if xyz_base is not None:
+        xb, xq = _f32(xyz_base.detach()), _f32(xyz_query.detach())
+        xN, xS = xb.shape[1], xq.shape[1]
+        dx = torch.empty(B, xS, k_xyz, dtype=torch.float32, device=dev)
+        ix = torch.empty(B, xS, k_xyz, dtype=torch.int64, device=dev)
+    df = torch.empty(B, S, k_feat, dtype=torch.float32, device=dev)
+    jf = torch.empty(B, S, k_feat, dtype=torch.int64, device=dev)
+    _launch("mpa_coarse_level_f32", _p(fin), B, fN, int(npoint or 0), _p(start), _p(fidx), _p(fxyz), _p(xb), _p(xq), xN, xS,
+            int(k_xyz or 0), _p(dx), _p(ix), _p(fb), _p(fq), N, S, C, k_feat, _p(df), _p(jf), _stream(),
+            algo_units=int(npoint or 0))
+    if xb is not None:
+        _memo_put(xb, xq, k_xyz, dx, ix)
+    return fidx, fxyz, (None if xb is None else (dx, ix)), (df, jf)
+
+
 def knn_xyz_and_feature(k_xyz, xyz_base, xyz_query, k_feat, feat_base, feat_query):
     """knn_point(k_xyz, xyz_base, xyz_query) and knn_point(k_feat, feat_base, feat_query) as ONE launch where the
     shapes allow (the fused kernel of fps_knn_fused without sampling workgroups), else as two.
@@ -413,6 +449,9 @@ def knn_xyz_and_feature(k_xyz, xyz_base, xyz_query, k_feat, feat_base, feat_quer
     fb, fq = _f32(feat_base.detach().float()), _f32(feat_query.detach().float())
     B, N, C = fb.shape
     S = fq.shape[1]
+    if _coarse_ok(None, xyz_base.shape[1], N, C, k_xyz, k_feat, fb, fq):
+        _, _, rx, rf = _coarse_level(None, None, None, k_xyz, xyz_base, xyz_query, k_feat, fb, fq)
+        return rx, rf
     ok = (FUSE_FPS_FEATURE_SEARCH and C in (64, 128) and k_feat <= 8 and k_xyz <= 8 and fb.data_ptr() % 16 == 0
           and fq.data_ptr() % 16 == 0)
     if not ok:
@@ -446,6 +485,9 @@ def fps_knn_fused(fps_in, npoint, k_xyz, xyz_base, xyz_query, k_feat, feat_base,
     B, N, C = fb.shape
     S = fq.shape[1]
     fN = fps_in.shape[1]
+    if fps_in.shape[2] == 3 and _coarse_ok(fN, None if xyz_base is None else xyz_base.shape[1], N, C,
+                                           None if xyz_base is None else k_xyz, k_feat, fb, fq):
+        return _coarse_level(fps_in, npoint, start_idx, k_xyz, xyz_base, xyz_query, k_feat, fb, fq)
     ok = (FUSE_FPS_FEATURE_SEARCH and C in (64, 128) and k_feat <= 8 and 128 < fN <= 2048 and fps_in.shape[2] == 3
           and fb.data_ptr() % 16 == 0 and fq.data_ptr() % 16 == 0 and (xyz_base is None or k_xyz <= 8))
     if not ok:

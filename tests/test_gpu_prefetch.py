@@ -136,3 +136,49 @@ def test_prefetched_step_equals_in_pass_chain(ops, monkeypatch):
         assert abs(ref[0][0] - ref[1][0]) > 1e-4           # (the batches are distinct: a stale geometry would show)
     finally:
         ops.set_deterministic(old)
+
+
+# ------------------------------------------------------------------------------- coarse states: one launch per state
+@pytest.mark.parametrize("B,fN,fS,xN,xS,N,S,C,K", [
+    (64, 128, 64, 256, 128, 256, 128, 64, 8),        # cls la3: 128 queries in 256 rows of 64 channels + FPS 128 -> 64
+    (64, 64, 32, 128, 64, 128, 64, 128, 8),          # cls la4
+    (64, None, None, 64, 32, 64, 32, 256, 8),        # cls la5: no next state
+    (3, 100, 33, 200, 77, 200, 77, 32, 5),           # ragged sizes, K = 5
+    (2, 50, 50, None, None, 40, 40, 128, 8),         # no coordinate search; K = 8 of 40
+    (2, None, None, 9, 9, 9, 9, 64, 8),              # fewer base rows than a tile, K = 8 of 9
+    (5, 128, 100, 256, 256, 256, 256, 256, 3),       # the largest base with the widest rows
+])
+def test_coarse_level_equals_separate_entry_points(ops, B, fN, fS, xN, xS, N, S, C, K):
+    """mpa_coarse_level_f32 (a coarse state's sampling + coordinate search + feature search as one launch of small
+    workgroups: whole base staged at once, one pass of MFMA distances, selection by 64-bit (distance, index) minima)
+    against farthest_point_sample / knn_point: indices and distance bits, including duplicated rows (exact ties ->
+    lowest index first)."""
+    g = torch.Generator().manual_seed(N * 7 + C)
+    fin = unit_cloud(B, fN, seed=fN).cuda() if fN else None
+    xb = unit_cloud(B, xN, seed=xN + 1).cuda() if xN else None
+    xq = xb[:, :xS].contiguous() if xN else None
+    fb = torch.randn(B, N, C, generator=g)
+    if N > 8:
+        fb[:, 5] = fb[:, 2]                      # a duplicated base row: an exact tie in every query's list
+    fb = fb.cuda()
+    fq = torch.cat((fb[:, :S // 2], torch.randn(B, S - S // 2, C, generator=g).cuda() * 0.7), 1).contiguous()
+    start = (torch.arange(B) * 3) % fN if fN else None
+    assert ops._coarse_ok(fN, xN, N, C, K if xN else None, K, fb, fq)
+    if fN:
+        fidx, fxyz, rx, (df, jf) = ops.fps_knn_fused(fin, fS, K, xb, xq, K, fb, fq, start_idx=start)
+        fidx0, fxyz0 = ops.farthest_point_sample(fin, fS, start_idx=start, return_xyz=True)
+        assert torch.equal(fidx, fidx0) and torch.equal(fxyz, fxyz0)
+    else:
+        rx, (df, jf) = ops.knn_xyz_and_feature(K, xb, xq, K, fb, fq)
+    ops.clear_knn_memo()
+    old = ops.set_fps_feature_fusion(False)
+    try:
+        df0, jf0 = ops.knn_point(K, fb, fq)
+        assert torch.equal(jf, jf0) and torch.equal(df, df0)
+        if xN:
+            dx0, ix0 = ops.knn_point(K, xb.clone(), xq)
+            assert torch.equal(rx[1], ix0) and torch.equal(rx[0], dx0)
+        else:
+            assert rx is None
+    finally:
+        ops.set_fps_feature_fusion(old)
