@@ -407,9 +407,11 @@ def set_fps_feature_fusion(on):
 
 def _coarse_ok(fN, xN, N, C, k_xyz, k_feat, fb, fq):
     """shapes of mpa_coarse_level_f32 (a coarse state's sampling + searches as one launch of small workgroups)"""
-    return (FUSE_FPS_FEATURE_SEARCH and C in (32, 64, 128, 256) and N <= 256 and (fN is None or fN <= 128)
-            and (xN is None or xN <= 256) and k_feat <= min(8, N) and (k_xyz is None or k_xyz <= 8)
-            and fb.data_ptr() % 16 == 0 and fq.data_ptr() % 16 == 0)
+    npad = (N + 31) // 32 * 32
+    lds = 4 * ((npad + 32) * (C + 4) + npad + 32 * (npad + 1))      # base + query rows, norms, 32 x N distances
+    return (FUSE_FPS_FEATURE_SEARCH and C in (32, 64, 128, 256) and N <= 256 and lds <= 160 * 1024
+            and (fN is None or fN <= 128) and (xN is None or xN <= 256) and k_feat <= min(8, N)
+            and (k_xyz is None or k_xyz <= min(8, xN)) and fb.data_ptr() % 16 == 0 and fq.data_ptr() % 16 == 0)
 
 
 def _coarse_level(fps_in, npoint, start_idx, k_xyz, xyz_base, xyz_query, k_feat, fb, fq):

@@ -146,7 +146,7 @@ def test_prefetched_step_equals_in_pass_chain(ops, monkeypatch):
     (3, 100, 33, 200, 77, 200, 77, 32, 5),           # ragged sizes, K = 5
     (2, 50, 50, None, None, 40, 40, 128, 8),         # no coordinate search; K = 8 of 40
     (2, None, None, 9, 9, 9, 9, 64, 8),              # fewer base rows than a tile, K = 8 of 9
-    (5, 128, 100, 256, 256, 256, 256, 256, 3),       # the largest base with the widest rows
+    (5, 128, 100, 256, 256, 96, 200, 256, 3),        # the widest rows: 96 of them fit the LDS (128 do not)
 ])
 def test_coarse_level_equals_separate_entry_points(ops, B, fN, fS, xN, xS, N, S, C, K):
     """mpa_coarse_level_f32 (a coarse state's sampling + coordinate search + feature search as one launch of small
