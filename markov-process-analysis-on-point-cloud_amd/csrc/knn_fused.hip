@@ -24,7 +24,14 @@ __global__ __launch_bounds__(256) void fps_knn2_kernel(const float *__restrict__
     extern __shared__ float lds[];
     int bid = blockIdx.x;
     if (bid < B) {
-        fps_body<4, P>(fxyz, fN, fS, start, f_idx, f_out_xyz, bid, lds);
+        // up to 512 points a single wave samples faster than four (no barrier per iteration: 0.33 against 0.39 us,
+        // fps.hip); the workgroup's other waves leave
+        if constexpr (P <= 2) {
+            if (threadIdx.x >= 64) return;
+            fps_body<1, 4 * P>(fxyz, fN, fS, start, f_idx, f_out_xyz, bid, lds);
+        } else {
+            fps_body<4, P>(fxyz, fN, fS, start, f_idx, f_out_xyz, bid, lds);
+        }
         return;
     }
     bid -= B;
