@@ -20,7 +20,7 @@ torch.manual_seed(0)
 args = argparse.Namespace(num_point=1024, return_dist=True, cuda_ops=True, num_class=40)
 model = Model(args).to(dev).train()
 crit = SmoothClsLoss()
-x, y = synthetic_batch(64, 1234, dev)
+x, y = synthetic_batch("cls", 64, 1024, 1234, dev)
 red = GradReducer(model, direct=True)
 red.overlap = False
 
