@@ -784,6 +784,7 @@ class _IndexPoints(torch.autograd.Function):
         _launch("mpa_gather_fwd_" + _sfx(points), _p(points), _p(flat), B, N, M, C, _p(out), _stream())
         ctx.save_for_backward(flat)
         ctx.shape = (B, N, M, C)
+        ctx.unique = idx.dim() == 2
         return out.view(*idx.shape, C)
 
     @staticmethod
@@ -791,9 +792,10 @@ class _IndexPoints(torch.autograd.Function):
         (flat,) = ctx.saved_tensors
         B, N, M, C = ctx.shape
         grad = grad.contiguous()
-        if grad.dtype == torch.bfloat16 and C % 2 == 0 and M <= N:
-            # index maps of at most N rows (the FPS maps: every row listed once): scattered straight into a bf16
-            # destination (no fp32 staging buffer, no cast)
+        if grad.dtype == torch.bfloat16 and C % 2 == 0 and M <= N and ctx.unique:
+            # [B,S] index maps of at most N rows (the FPS maps: every row listed once): scattered straight into a bf16
+            # destination (no fp32 staging buffer, no cast).  Neighbour lists [B,S,K] repeat rows: their sums stay fp32
+            # (a compare-and-swap that rounds to bf16 after every add would depend on the order of the adds)
             gp = torch.zeros(B, N, C, dtype=torch.bfloat16, device=grad.device)
             _launch("mpa_gather_bwd_into_bf16", _p(grad), _p(flat), B, N, M, C, _p(gp), _stream())
             return gp, None
