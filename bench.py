@@ -135,9 +135,8 @@ def forward_only(run_forward, feeder, arena, batch, iters=50):
     """Forward pass alone (train-mode BatchNorm statistics, no autograd), captured as a HIP graph: a
     secondary figure next to the headline fwd+bwd metric (SURVEY 8d states the >= 20x target on it)."""
     from mpa_amd import ops
-    saved_prefetch = ops.set_geometry_prefetch(None)       # forward alone: the sampling chain runs inside the pass
 
-    def one_pass():
+    def one_pass():             # (the sampling chain runs inside the pass: no step's prefetch object is installed here)
         feeder.begin_pass()
         arena.begin()
         ops.set_arena(arena)
@@ -169,7 +168,6 @@ def forward_only(run_forward, feeder, arena, batch, iters=50):
             g.replay()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / iters
-    ops.set_geometry_prefetch(saved_prefetch)
     return {"value": batch / dt, "unit": "point-clouds/s", "ms_per_step": dt * 1e3, "steps": iters}
 
 

@@ -96,13 +96,16 @@ __global__ __launch_bounds__(256) void smooth_loss_fwd_kernel(const float *__res
     if (threadIdx.x == 0) partial[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
 }
 
-__global__ __launch_bounds__(64) void smooth_loss_finish_kernel(const float *__restrict__ partial, int nblocks,
-                                                                float inv_M, float *__restrict__ loss)
+__global__ __launch_bounds__(256) void smooth_loss_finish_kernel(const float *__restrict__ partial, int nblocks,
+                                                                 float inv_M, float *__restrict__ loss)
 {
+    __shared__ float wsum[4];
     float s = 0.f;
-    for (int i = threadIdx.x; i < nblocks; i += 64) s += partial[i];
+    for (int i = threadIdx.x; i < nblocks; i += 256) s += partial[i];
     s = wave_sum_f32(s);
-    if (threadIdx.x == 0) loss[0] = s * inv_M;
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) loss[0] = ((wsum[0] + wsum[1]) + (wsum[2] + wsum[3])) * inv_M;
 }
 
 // d loss / d x, scaled by the upstream gradient g[0]:  LOGITS: (softmax(x) - w) / M;  log-probabilities: -w / M
@@ -181,9 +184,13 @@ extern "C" int mpa_log_softmax_bwd_f32(const float *y, const float *grad_y, int 
     return MPA_OK;
 }
 
+// rows per block: 16 (four per wave) keeps every CU busy from a few thousand rows on and a 64-row classification batch on
+// four workgroups; the second kernel adds the <= M/16 block sums in a fixed order
+static inline int smooth_loss_rows_per_block(int M) { return M > (1 << 20) ? 64 : 16; }
+
 extern "C" int mpa_smooth_loss_workspace_floats(int M)
 {
-    const int rows_per_block = M <= 1024 ? 1024 : 256;
+    const int rows_per_block = smooth_loss_rows_per_block(M);
     return (M + rows_per_block - 1) / rows_per_block;
 }
 
@@ -193,7 +200,7 @@ extern "C" int mpa_smooth_loss_fwd_f32(const float *x, const int64_t *target, in
     MPA_CLEAR_ERROR();
     if (!x || !target || !partial || !loss || M <= 0 || C <= 1 || (from_logits && !lse)) return MPA_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    const int rows_per_block = M <= 1024 ? 1024 : 256;
+    const int rows_per_block = smooth_loss_rows_per_block(M);
     const int nblocks = (M + rows_per_block - 1) / rows_per_block;
     if (from_logits)
         hipLaunchKernelGGL(smooth_loss_fwd_kernel<true>, dim3(nblocks), dim3(256), 0, st, x, target, M, C, eps,
@@ -201,7 +208,7 @@ extern "C" int mpa_smooth_loss_fwd_f32(const float *x, const int64_t *target, in
     else
         hipLaunchKernelGGL(smooth_loss_fwd_kernel<false>, dim3(nblocks), dim3(256), 0, st, x, target, M, C, eps,
                            rows_per_block, lse, partial);
-    hipLaunchKernelGGL(smooth_loss_finish_kernel, dim3(1), dim3(64), 0, st, partial, nblocks, 1.f / (float)M, loss);
+    hipLaunchKernelGGL(smooth_loss_finish_kernel, dim3(1), dim3(256), 0, st, partial, nblocks, 1.f / (float)M, loss);
     MPA_LAUNCH_CHECK();
     return MPA_OK;
 }

@@ -1124,11 +1124,13 @@ __global__ __launch_bounds__(256) void group_col_sum_kernel(const T *__restrict_
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     if (c < C) {
         int r = rl;
-        for (; r + 12 < R; r += 16) {
-            a0 += mpa_ld1<T>(base + (size_t)r * ld + c);
-            a1 += mpa_ld1<T>(base + (size_t)(r + 4) * ld + c);
-            a2 += mpa_ld1<T>(base + (size_t)(r + 8) * ld + c);
-            a3 += mpa_ld1<T>(base + (size_t)(r + 12) * ld + c);
+        // 16 rows in flight per lane (4 made the 2048 rows of a part-seg cloud 128 dependent round trips: 68 us)
+        for (; r + 60 < R; r += 64) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = mpa_ld1<T>(base + (size_t)(r + 4 * u) * ld + c);
+#pragma unroll
+            for (int u = 0; u < 16; u += 4) { a0 += v[u]; a1 += v[u + 1]; a2 += v[u + 2]; a3 += v[u + 3]; }
         }
         for (; r < R; r += 4) a0 += mpa_ld1<T>(base + (size_t)r * ld + c);
     }

@@ -139,7 +139,8 @@ class GraphedTrainStep:
         self.prefetch = ops.GeometryPrefetch() if prefetch_geometry else None
         self.coords_of = coords_of or (lambda batch: batch[0][:, :3])
         self._announced = None                   # (tensor, version) of the batch whose geometry the buffers hold
-        self._saved_prefetch = ops.set_geometry_prefetch(self.prefetch) if self.prefetch is not None else None
+        # (the prefetch object is installed only while one of THIS step's passes runs, _fwd_bwd: any other forward of
+        # the model -- an evaluation between steps -- must run its own chain, not read another batch's geometry)
 
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -148,8 +149,7 @@ class GraphedTrainStep:
             if self.prefetch is not None:
                 pf = self.prefetch
                 if pf.spec is None or not pf.supported():
-                    ops.set_geometry_prefetch(self._saved_prefetch)          # no chain in this model / unsupported shape
-                    self.prefetch = None
+                    self.prefetch = None                                     # no chain in this model / unsupported shape
                 else:
                     pf.allocate(self.static[0].device)
                     pf.next_xyz.copy_(self.coords_of(self.static).transpose(1, 2))
@@ -185,6 +185,7 @@ class GraphedTrainStep:
         self.reducer.zero_grad()
         self.arena.begin()
         ops.set_arena(self.arena)
+        saved_prefetch = ops.set_geometry_prefetch(self.prefetch)
         try:
             if self.compute_loss is not None:
                 loss = self.compute_loss(self.model, self.loss_fn, *self.static)
@@ -194,6 +195,7 @@ class GraphedTrainStep:
             self.feeder.end_pass()
             ops.set_arena(None)
             self.arena.end()
+            ops.set_geometry_prefetch(saved_prefetch)
         ops.defer_weight_grads(True)          # dW products are queued during backward ...
         try:
             loss.backward()
@@ -233,5 +235,3 @@ class GraphedTrainStep:
 
     def close(self):
         ops.set_fps_start_hook(None)
-        if self.prefetch is not None:
-            ops.set_geometry_prefetch(self._saved_prefetch)

@@ -121,6 +121,8 @@ def test_prefetched_step_equals_in_pass_chain(ops, monkeypatch):
                     nxt = batches[order[t + 1]] if t + 1 < len(order) and t != 3 else None     # step 3 announces nothing:
                     loss = step(*batches[bi], next_batch=nxt)                                  # -> step 4's batch is computed on the spot
                     torch.cuda.synchronize()
+                    assert ops._PREFETCH is None        # installed only inside the step's own passes: any other forward
+                                                        # of the model (an evaluation between steps) runs its own chain
                     out.append((float(loss), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}))
             finally:
                 step.close()
