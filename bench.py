@@ -314,9 +314,14 @@ def run_config(name, a, world, rank, dev, steps, warmup, headline):
         # all-reduce them INSIDE the captured graph, overlapped with the rest of backward.  Off by default: RCCL under
         # graph capture has run on one rank only (tests/test_gpu_rccl_capture.py), never across GPUs.
         cap = world > 1 and os.environ.get("MPA_CAPTURE_REDUCE") == "1" and w["split"] is not None
-        # MPA_PREFETCH=1: the next batch's sampling chain rides in this step's weight-gradient launches
-        # (ops.GeometryPrefetch).  Off by default: measured 3.83 ms against 3.70 ms per cls-fp32 step.
-        prefetch = w["has_chain"] and not cap and os.environ.get("MPA_PREFETCH") == "1"
+        # Cross-step geometry (ops.GeometryPipeline): the NEXT batch's sampling chain and state-0 search ride in this
+        # batch's search launches (the step announces its next batch).  On by default where the shapes allow (clouds of
+        # <= 2048 points): 3.51 against 3.56 ms per cls-fp32 step.  MPA_PREFETCH=0: the chain inside the pass;
+        # MPA_PREFETCH=riders: the first form (riders in the weight-gradient launches: slower).
+        mode = os.environ.get("MPA_PREFETCH", "1")
+        prefetch = False
+        if w["has_chain"] and not cap and mode != "0":
+            prefetch = "riders" if mode == "riders" else True
         graphed = GraphedTrainStep(model, crit, data, lr=1e-3, compute_loss=w["compute_loss"],
                                    split_after=w["split"] if cap else None, capture_reduce=cap,
                                    prefetch_geometry=prefetch)                                    # optim.FlatAdam
@@ -453,8 +458,9 @@ def run_config(name, a, world, rank, dev, steps, warmup, headline):
                            "launch": "eager" if eager else "hipgraph",
                            "batches": "two distinct resident synthetic batches per rank, alternating every step (copied "
                                       "into the graph's static buffers inside the timed region)" + (
-                               "; each step announces the next batch, whose FPS chain and first two coordinate searches "
-                               "run in this step's weight-gradient launches (ops.GeometryPrefetch)"
+                               "; each step announces the next batch, whose FPS chain and state-0 coordinate search "
+                               "ride in this step's %s" % ("search launches (ops.GeometryPipeline)" if type(graphed.prefetch).__name__
+                                                           == "GeometryPipeline" else "weight-gradient launches (ops.GeometryPrefetch)")
                                if (graphed is not None and graphed.prefetch is not None) else "")},
                 "roofline": roof,
                 "roofline_other_kernels": kernels[1:],

@@ -242,8 +242,18 @@ typedef struct MpaGemmTnProblem {
 } MpaGemmTnProblem;
 int mpa_gemm_tn_grouped_f32(const MpaGemmTnProblem *problems, int count, float *workspace,
                             size_t workspace_bytes, void *stream);
+/* mpa_fps_knn_feat_f32 with a SECOND coordinate search (xyz2_*: base [B,zN,3], query [B,zS,3], zK <= 8; NULL: none) in
+ * the same launch -- round 3: the sampling and the state-0 search of the NEXT batch ride beside this batch's state-1
+ * searches (cross-step pipelining of the geometry, ops.GeometryPipeline; reference modules/repsurface_utils.py:581-619).
+ * fps_xyz == NULL: no sampling workgroups.  Every result equals the stand-alone entry point's bit for bit. */
+int mpa_geo_level_f32(const float *fps_xyz, int B, int fps_N, int fps_S, const int64_t *start_idx,
+                      int64_t *fps_idx, float *fps_out_xyz, const float *xyz_base, const float *xyz_query,
+                      int xN, int xS, int xK, float *xyz_dist, int64_t *xyz_idx, const float *xyz2_base,
+                      const float *xyz2_query, int zN, int zS, int zK, float *xyz2_dist, int64_t *xyz2_idx,
+                      const float *feat_base, const float *feat_norms, const float *feat_query, int N, int S, int C,
+                      int K, float *out_dist, int64_t *out_idx, void *stream);
 /* A COARSE state's geometry step in one launch (csrc/knn_fused.hip): the sampling of the next state (optional:
- * fps_xyz != NULL; fps_S from fps_N <= 128 points), the coordinate search (optional: xyz_base != NULL; xN <= 256) and
+ * fps_xyz != NULL; fps_S from fps_N <= 256 points), the coordinate search (optional: xyz_base != NULL; xN <= 256) and
  * the feature-space search (N <= 256 base rows of C in {32,64,128,256} floats, 16-byte aligned), all K <= 8 -- the
  * last states of a chain (128 -> 64 -> 32 points in the classification model), where every launch of the general
  * kernels is latency.  Same outputs, bit for bit, as mpa_fps_f32 + mpa_knn_f32 x 2.  MPA_EUNSUPPORTED outside these

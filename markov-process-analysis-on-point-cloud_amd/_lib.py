@@ -141,6 +141,8 @@ SIGNATURES.update({
     "mpa_three_interp_bwd_bf16": SIGNATURES["mpa_three_interp_bwd_f32"],
 })
 
+SIGNATURES["mpa_geo_level_f32"] = ([_vp, _i, _i, _i, _vp, _vp, _vp] + [_vp, _vp, _i, _i, _i, _vp, _vp] * 2 +
+                                   [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp])
 SIGNATURES["mpa_coarse_level_f32"] = [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i,
                                       _i, _vp, _vp, _vp]
 SIGNATURES.update({

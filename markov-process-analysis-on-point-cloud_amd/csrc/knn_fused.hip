@@ -14,13 +14,27 @@ struct FusedSearch {
     float *dist;
     int64_t *idx;
     int N, S, K, qb, blocks;               // qb: query workgroups per cloud
+    int res;                               // coordinate searches: base cloud resident in LDS (both passes out of LDS)
 };
+
+// coordinate search of a fused launch: resident when the cloud fits the launch's LDS (a C = 3 tile visit out of LDS
+// instead of a global round trip: the state-0 search of a 1024-point batch is 64 us resident, ~4x that otherwise)
+__device__ __forceinline__ void fused_xyz_search(const FusedSearch &x, const int bid, float *lds)
+{
+    if (x.res)
+        knn_mfma_body<3, 4, 8, 1, true, false>(x.base, x.query, x.N, x.S, x.K, x.dist, x.idx, bid % x.qb, bid / x.qb, lds);
+    else
+        knn_mfma_body<3, 4, 8, 1, false, false>(x.base, x.query, x.N, x.S, x.K, x.dist, x.idx, bid % x.qb, bid / x.qb, lds);
+}
 
 template <int P, int CT, int QG, bool GN>
 __global__ __launch_bounds__(256) void fps_knn2_kernel(const float *__restrict__ fxyz, int fN, int fS,
                                                        const int64_t *__restrict__ start, int64_t *__restrict__ f_idx,
-                                                       float *__restrict__ f_out_xyz, int B, FusedSearch x, FusedSearch y)
+                                                       float *__restrict__ f_out_xyz, int B, FusedSearch x, FusedSearch y,
+                                                       FusedSearch z)
 {
+    // z: a second coordinate search (round 3: the NEXT batch's state-0 search, carried beside this batch's state-1
+    // searches together with the next batch's level-1 sampling: ops.GeometryPipeline)
     extern __shared__ float lds[];
     int bid = blockIdx.x;
     if (bid < B) {
@@ -35,11 +49,18 @@ __global__ __launch_bounds__(256) void fps_knn2_kernel(const float *__restrict__
         return;
     }
     bid -= B;
+    // (the many short coordinate-search workgroups first, the long feature-search workgroups last: the other order was
+    // measured slower, 3.535 against 3.511 ms per classification step in the cross-step pipeline)
     if (bid < x.blocks) {
-        knn_mfma_body<3, 4, 8, 1, false, false>(x.base, x.query, x.N, x.S, x.K, x.dist, x.idx, bid % x.qb, bid / x.qb, lds);
+        fused_xyz_search(x, bid, lds);
         return;
     }
     bid -= x.blocks;
+    if (bid < z.blocks) {
+        fused_xyz_search(z, bid, lds);
+        return;
+    }
+    bid -= z.blocks;
     knn_mfma_body<CT, 4, 8, QG, false, GN>(y.base, y.query, y.N, y.S, y.K, y.dist, y.idx, bid % y.qb, bid / y.qb, lds,
                                            y.norms);
 }
@@ -55,35 +76,44 @@ constexpr size_t feat_lds_bytes()
 
 template <int P, int CT, int QG, bool GN>
 int launch_fused(const float *fxyz, int B, int fN, int fS, const int64_t *start, int64_t *f_idx, float *f_out_xyz,
-                 const FusedSearch &x, const FusedSearch &y, hipStream_t st)
+                 const FusedSearch &x_in, const FusedSearch &y, const FusedSearch &z_in, hipStream_t st)
 {
     constexpr size_t xyz_lds = ((size_t)4 * (32 * (4 + 4) + 32) + KNN_G * 32 + 32 + 64 + 2 * 32 * KNN_CAP) * sizeof(float);
     constexpr size_t fps_lds = (size_t)3 * 256 * P * sizeof(float) + 2 * 4 * sizeof(uint2);
     constexpr size_t a = feat_lds_bytes<CT, QG>() > xyz_lds ? feat_lds_bytes<CT, QG>() : xyz_lds;
-    constexpr size_t lds = a > fps_lds ? a : fps_lds;
-    static_assert(lds <= 160 * 1024, "LDS of a gfx950 CU");
+    constexpr size_t lds0 = a > fps_lds ? a : fps_lds;
+    static_assert(lds0 <= 160 * 1024, "LDS of a gfx950 CU");
+    // resident coordinate searches when the cloud fits what the launch allocates anyway
+    FusedSearch x = x_in, z = z_in;
+    auto resident = [&](FusedSearch &s) {
+        const size_t need = xyz_lds + (size_t)mpa_ceil_div(s.N, 32) * 32 * 5 * sizeof(float);
+        s.res = (s.blocks > 0 && s.N <= KNN_RES_MAX && need <= lds0) ? 1 : 0;
+    };
+    resident(x);
+    resident(z);
+    constexpr size_t lds = lds0;
     if (lds > 64 * 1024) {
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_knn2_kernel<P, CT, QG, GN>),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (attr != hipSuccess) return MPA_EHIP;
     }
-    const long long blocks = (long long)B + x.blocks + y.blocks;
+    const long long blocks = (long long)B + x.blocks + y.blocks + z.blocks;
     if (blocks >= 0x7fffffffLL) return MPA_EUNSUPPORTED;
     hipLaunchKernelGGL((fps_knn2_kernel<P, CT, QG, GN>), dim3((unsigned)blocks), dim3(256), lds, st, fxyz, fN, fS, start,
-                       f_idx, f_out_xyz, B, x, y);
+                       f_idx, f_out_xyz, B, x, y, z);
     MPA_LAUNCH_CHECK();
     return MPA_OK;
 }
 
 template <int CT, int QG, bool GN>
 int launch_fused_p(int P, const float *fxyz, int B, int fN, int fS, const int64_t *start, int64_t *f_idx,
-                   float *f_out_xyz, const FusedSearch &x, const FusedSearch &y, hipStream_t st)
+                   float *f_out_xyz, const FusedSearch &x, const FusedSearch &y, const FusedSearch &z, hipStream_t st)
 {
     switch (P) {
-    case 1: return launch_fused<1, CT, QG, GN>(fxyz, B, fN, fS, start, f_idx, f_out_xyz, x, y, st);
-    case 2: return launch_fused<2, CT, QG, GN>(fxyz, B, fN, fS, start, f_idx, f_out_xyz, x, y, st);
-    case 4: return launch_fused<4, CT, QG, GN>(fxyz, B, fN, fS, start, f_idx, f_out_xyz, x, y, st);
-    default: return launch_fused<8, CT, QG, GN>(fxyz, B, fN, fS, start, f_idx, f_out_xyz, x, y, st);
+    case 1: return launch_fused<1, CT, QG, GN>(fxyz, B, fN, fS, start, f_idx, f_out_xyz, x, y, z, st);
+    case 2: return launch_fused<2, CT, QG, GN>(fxyz, B, fN, fS, start, f_idx, f_out_xyz, x, y, z, st);
+    case 4: return launch_fused<4, CT, QG, GN>(fxyz, B, fN, fS, start, f_idx, f_out_xyz, x, y, z, st);
+    default: return launch_fused<8, CT, QG, GN>(fxyz, B, fN, fS, start, f_idx, f_out_xyz, x, y, z, st);
     }
 }
 
@@ -243,18 +273,19 @@ __global__ __launch_bounds__(256) void coarse_level_kernel(const float *__restri
     int bid = blockIdx.x;
     if (bid < fB) {
         // one wave samples (the cloud in registers, no barrier inside the loop); the others leave
-        float *sx = lds, *sy = lds + 128, *sz = lds + 256;
+        float *sx = lds, *sy = lds + 256, *sz = lds + 512;
         const float *cloud = fxyz + (size_t)bid * fN * 3;
         for (int i = threadIdx.x; i < fN * 3; i += 256) {
             const int n = i / 3;
-            lds[(i - 3 * n) * 128 + n] = cloud[i];
+            lds[(i - 3 * n) * 256 + n] = cloud[i];
         }
         __syncthreads();
         if (threadIdx.x >= 64) return;
         int64_t *oi = f_idx + (size_t)bid * fS;
         float *ox = f_out_xyz + (size_t)bid * fS * 3;
         if (fN <= 64) fps_level<1, 1>(sx, sy, sz, fN, fS, (int)start[bid], oi, ox, nullptr, nullptr, nullptr, nullptr);
-        else fps_level<1, 2>(sx, sy, sz, fN, fS, (int)start[bid], oi, ox, nullptr, nullptr, nullptr, nullptr);
+        else if (fN <= 128) fps_level<1, 2>(sx, sy, sz, fN, fS, (int)start[bid], oi, ox, nullptr, nullptr, nullptr, nullptr);
+        else fps_level<1, 4>(sx, sy, sz, fN, fS, (int)start[bid], oi, ox, nullptr, nullptr, nullptr, nullptr);
         return;
     }
     bid -= fB;
@@ -272,7 +303,7 @@ int launch_coarse(const float *fxyz, int fB, int fN, int fS, const int64_t *star
 {
     size_t lds = small_lds_bytes<CT>(y.N);
     if (x.blocks > 0 && small_lds_bytes<3>(x.N) > lds) lds = small_lds_bytes<3>(x.N);
-    if (lds < 3 * 128 * sizeof(float)) lds = 3 * 128 * sizeof(float);
+    if (lds < 3 * 256 * sizeof(float)) lds = 3 * 256 * sizeof(float);
     if (lds > 160 * 1024) return MPA_EUNSUPPORTED;
     if (lds > 64 * 1024) {
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&coarse_level_kernel<CT>),
@@ -287,7 +318,7 @@ int launch_coarse(const float *fxyz, int fB, int fN, int fS, const int64_t *star
 
 }  // namespace
 
-// A coarse state's geometry step in one launch (see above): optional sampling of fps_S from fps_N <= 128 points,
+// A coarse state's geometry step in one launch (see above): optional sampling of fps_S from fps_N <= 256 points,
 // optional coordinate search (xN <= 256), feature search with N <= 256 rows of C in {32, 64, 128, 256} floats, K <= 8.
 // MPA_EUNSUPPORTED outside those shapes.  Results are bit-identical to mpa_fps_f32 / mpa_knn_f32.
 extern "C" int mpa_coarse_level_f32(const float *fps_xyz, int B, int fps_N, int fps_S, const int64_t *start_idx,
@@ -302,7 +333,7 @@ extern "C" int mpa_coarse_level_f32(const float *fps_xyz, int B, int fps_N, int 
     if (sample && (!start_idx || !fps_idx || !fps_out_xyz || fps_N <= 0 || fps_S <= 0)) return MPA_EINVAL;
     if (xyz_base && (!xyz_query || !xyz_idx || xN <= 0 || xS <= 0 || xK <= 0)) return MPA_EINVAL;
     if (K > 8 || K > N || N > SMALL_MAX_N || (xyz_base && (xK > 8 || xK > xN || xN > SMALL_MAX_N)) ||
-        (sample && fps_N > 128) || (((uintptr_t)feat_base | (uintptr_t)feat_query) & 15) != 0)
+        (sample && fps_N > 256) || (((uintptr_t)feat_base | (uintptr_t)feat_query) & 15) != 0)
         return MPA_EUNSUPPORTED;
     SmallSearch x, y;
     x.base = xyz_base; x.query = xyz_query; x.dist = xyz_dist; x.idx = xyz_idx; x.N = xN; x.S = xS; x.K = xK;
@@ -326,7 +357,21 @@ extern "C" int mpa_fps_knn_feat_f32(const float *fps_xyz, int B, int fps_N, int 
                                     const float *feat_base, const float *feat_norms, const float *feat_query, int N,
                                     int S, int C, int K, float *out_dist, int64_t *out_idx, void *stream)
 {
+    return mpa_geo_level_f32(fps_xyz, B, fps_N, fps_S, start_idx, fps_idx, fps_out_xyz, xyz_base, xyz_query, xN, xS, xK,
+                             xyz_dist, xyz_idx, nullptr, nullptr, 0, 0, 0, nullptr, nullptr, feat_base, feat_norms,
+                             feat_query, N, S, C, K, out_dist, out_idx, stream);
+}
+
+extern "C" int mpa_geo_level_f32(const float *fps_xyz, int B, int fps_N, int fps_S, const int64_t *start_idx,
+                                 int64_t *fps_idx, float *fps_out_xyz, const float *xyz_base, const float *xyz_query,
+                                 int xN, int xS, int xK, float *xyz_dist, int64_t *xyz_idx, const float *xyz2_base,
+                                 const float *xyz2_query, int zN, int zS, int zK, float *xyz2_dist, int64_t *xyz2_idx,
+                                 const float *feat_base, const float *feat_norms, const float *feat_query, int N, int S,
+                                 int C, int K, float *out_dist, int64_t *out_idx, void *stream)
+{
     MPA_CLEAR_ERROR();
+    if (xyz2_base && (!xyz2_query || !xyz2_idx || !xyz2_dist || zN <= 0 || zS <= 0 || zK <= 0)) return MPA_EINVAL;
+    if (xyz2_base && (zK > 8 || zK > zN)) return MPA_EUNSUPPORTED;
     // fps_xyz == NULL: no sampling workgroups -- the two searches of a state alone in one launch (the sampling chain
     // of that pass was computed a step ahead by geometry riders, mpa_gemm_tn_grouped_rider_f32)
     const bool sample = fps_xyz != nullptr;
@@ -344,13 +389,16 @@ extern "C" int mpa_fps_knn_feat_f32(const float *fps_xyz, int B, int fps_N, int 
     x.N = xN; x.S = xS; x.K = xK; x.qb = xyz_base ? mpa_ceil_div(xS, 32) : 1; x.blocks = xyz_base ? x.qb * B : 0;
     y.base = feat_base; y.query = feat_query; y.norms = feat_norms; y.dist = out_dist; y.idx = out_idx;
     y.N = N; y.S = S; y.K = K;
+    FusedSearch z;
+    z.base = xyz2_base; z.query = xyz2_query; z.norms = nullptr; z.dist = xyz2_dist; z.idx = xyz2_idx;
+    z.N = zN; z.S = zS; z.K = zK; z.qb = xyz2_base ? mpa_ceil_div(zS, 32) : 1; z.blocks = xyz2_base ? z.qb * B : 0;
     hipStream_t st = (hipStream_t)stream;
     if (C == 64 && feat_norms != nullptr) {                      // two query groups per workgroup (needs the norms)
         y.qb = mpa_ceil_div(S, 64); y.blocks = y.qb * B;
-        return launch_fused_p<64, 2, true>(P, fps_xyz, fB, fps_N, fps_S, start_idx, fps_idx, fps_out_xyz, x, y, st);
+        return launch_fused_p<64, 2, true>(P, fps_xyz, fB, fps_N, fps_S, start_idx, fps_idx, fps_out_xyz, x, y, z, st);
     }
     y.qb = mpa_ceil_div(S, 32); y.blocks = y.qb * B;
     y.norms = nullptr;
-    if (C == 64) return launch_fused_p<64, 1, false>(P, fps_xyz, fB, fps_N, fps_S, start_idx, fps_idx, fps_out_xyz, x, y, st);
-    return launch_fused_p<128, 1, false>(P, fps_xyz, fB, fps_N, fps_S, start_idx, fps_idx, fps_out_xyz, x, y, st);
+    if (C == 64) return launch_fused_p<64, 1, false>(P, fps_xyz, fB, fps_N, fps_S, start_idx, fps_idx, fps_out_xyz, x, y, z, st);
+    return launch_fused_p<128, 1, false>(P, fps_xyz, fB, fps_N, fps_S, start_idx, fps_idx, fps_out_xyz, x, y, z, st);
 }

@@ -405,12 +405,71 @@ def set_fps_feature_fusion(on):
     return old
 
 
+def geo_level(fps_src, npoint, start, fps_idx_out, fps_xyz_out, k_xyz, xyz_base, xyz_query, extra, k_feat, feat_base,
+              feat_query):
+    """One state's launch in the cross-step pipeline (GeometryPipeline): farthest_point_sample(fps_src, npoint) INTO the
+    given buffers (another batch's coordinates), knn_point(k_xyz, xyz_base, xyz_query), an optional second coordinate
+    search extra = (base, query, k, dist_out, idx_out) into given buffers, and knn_point(k_feat, feat_base, feat_query) --
+    as one launch where the shapes allow (mpa_geo_level_f32 / mpa_coarse_level_f32), else as the separate entry points.
+    -> ((dist, idx), (dist_f, idx_f)); every result equals the separate calls' bit for bit."""
+    _dev(fps_src, xyz_base, feat_base)
+    fb, fq = _f32(feat_base.detach().float()), _f32(feat_query.detach().float())
+    B, N, C = fb.shape
+    S = fq.shape[1]
+    fin = _f32(fps_src.detach())
+    fN = fin.shape[1]
+    dev = fb.device
+    xb, xq = _f32(xyz_base.detach()), _f32(xyz_query.detach())
+    xN, xS = xb.shape[1], xq.shape[1]
+    coarse = extra is None and _coarse_ok(fN, xN, N, C, k_xyz, k_feat, fb, fq) and fN <= 256
+    regular = (FUSE_FPS_FEATURE_SEARCH and C in (64, 128) and k_feat <= 8 and k_xyz <= 8 and 128 < fN <= 2048
+               and fb.data_ptr() % 16 == 0 and fq.data_ptr() % 16 == 0 and (extra is None or extra[2] <= 8))
+    if not (coarse or regular):
+        idx, x = farthest_point_sample(fin, npoint, start_idx=start, return_xyz=True)
+        fps_idx_out.copy_(idx)
+        fps_xyz_out.copy_(x)
+        if extra is not None:
+            d, i = knn_point(extra[2], extra[0], extra[1])
+            extra[3].copy_(d)
+            extra[4].copy_(i)
+        return knn_point(k_xyz, xb, xq), knn_point(k_feat, fb, fq)
+    dx = torch.empty(B, xS, k_xyz, dtype=torch.float32, device=dev)
+    ix = torch.empty(B, xS, k_xyz, dtype=torch.int64, device=dev)
+    df = torch.empty(B, S, k_feat, dtype=torch.float32, device=dev)
+    jf = torch.empty(B, S, k_feat, dtype=torch.int64, device=dev)
+    if coarse:
+        _launch("mpa_coarse_level_f32", _p(fin), B, fN, int(npoint), _p(start), _p(fps_idx_out), _p(fps_xyz_out), _p(xb), _p(xq),
+                xN, xS, int(k_xyz), _p(dx), _p(ix), _p(fb), _p(fq), N, S, C, k_feat, _p(df), _p(jf), _stream(),
+                algo_units=int(npoint))
+    else:
+        norms = None
+        if C == 64 and (S + 31) // 32 * B >= 1024 and not PIPELINE_ONE_QUERY_GROUP:
+            norms = torch.empty(B, (N + 31) // 32 * 32, dtype=torch.float32, device=dev)
+            _launch("mpa_row_norms_f32", _p(fb), B, N, C, _p(norms), _stream())
+        zb = zq = zd = zi = None
+        zN = zS = zK = 0
+        if extra is not None:
+            zb, zq = _f32(extra[0].detach()), _f32(extra[1].detach())
+            zN, zS, zK, zd, zi = zb.shape[1], zq.shape[1], int(extra[2]), extra[3], extra[4]
+        _launch("mpa_geo_level_f32", _p(fin), B, fN, int(npoint), _p(start), _p(fps_idx_out), _p(fps_xyz_out), _p(xb), _p(xq),
+                xN, xS, int(k_xyz), _p(dx), _p(ix), _p(zb), _p(zq), zN, zS, zK, _p(zd), _p(zi), _p(fb), _p(norms), _p(fq), N,
+                S, C, k_feat, _p(df), _p(jf), _stream(), algo_units=int(npoint))
+    _memo_put(xb, xq, k_xyz, dx, ix)
+    return (dx, ix), (df, jf)
+
+
+# development switch: one 32-query group per workgroup for the state-1 feature search that carries the next batch's
+# level-1 sampling (more, shorter workgroups around the 64 sampling ones)
+PIPELINE_ONE_QUERY_GROUP = os.environ.get("MPA_PIPELINE_QG1") == "1"
+PIPELINE_KNN0_LEVEL = int(os.environ.get("MPA_PIPELINE_KNN0", "1"))     # which state's launch carries the next batch's state-0 search
+
+
 def _coarse_ok(fN, xN, N, C, k_xyz, k_feat, fb, fq):
     """shapes of mpa_coarse_level_f32 (a coarse state's sampling + searches as one launch of small workgroups)"""
     npad = (N + 31) // 32 * 32
     lds = 4 * ((npad + 32) * (C + 4) + npad + 32 * (npad + 1))      # base + query rows, norms, 32 x N distances
     return (FUSE_FPS_FEATURE_SEARCH and C in (32, 64, 128, 256) and N <= 256 and lds <= 160 * 1024
-            and (fN is None or fN <= 128) and (xN is None or xN <= 256) and k_feat <= min(8, N)
+            and (fN is None or fN <= 256) and (xN is None or xN <= 256) and k_feat <= min(8, N)
             and (k_xyz is None or k_xyz <= min(8, xN)) and fb.data_ptr() % 16 == 0 and fq.data_ptr() % 16 == 0)
 
 
@@ -539,6 +598,7 @@ class GeometryChain:
         g = _GeoLevel()
         g.xyz, g.chain, g.i = xyz, self, 0
         self.levels = [g] + [None] * len(self.npoints)
+        self.pipe = None
         pf = _PREFETCH
         if pf is not None and pf.enabled:
             if pf.spec is None:
@@ -556,6 +616,10 @@ class GeometryChain:
         """Issue whatever of (next state's FPS, this state's coordinate search, feature search) is still due."""
         i, L = g.i, len(self.npoints)
         base = self.levels[i - 1].xyz if i > 0 else g.xyz
+        if self.pipe is not None and i >= 1 and feature is not None and g.idx is None:
+            with torch.no_grad():
+                (g.dist, g.idx), (_, idx_f) = self.pipe.level_launch(self, i, base, g.xyz, k_feat, feature, query)
+            return idx_f
         need_xyz = g.idx is None
         need_fps = i < L and self.levels[i + 1] is None
         idx_f = None
@@ -695,6 +759,125 @@ class GeometryPrefetch:
         arr = self._riders(xyz, self._draw_starts(xyz.device))
         for i in range(2):
             _launch("mpa_geo_rider_f32", ctypes.byref(arr[i]), _stream())
+        self.ready = True
+
+
+class GeometryPipeline:
+    """Cross-step geometry carried by the SEARCH launches (round 3, second form; the first, GeometryPrefetch above, rides in
+    the weight-gradient launches and is slower: MFMA workgroups on the same CU slow the sampling waves 2.3x, search
+    workgroups do not -- the in-pass launches have always mixed the two).
+
+    In a pass over batch t, the launch of state i's searches (i = 1..L) carries, as its first B workgroups, level i of the
+    sampling chain of batch t+1 -- level 1 from the next batch's coordinates, level i from level i-1's result, which the
+    launch of state i-1 has just produced -- and the launch of state 1 also carries batch t+1's state-0 search.  So
+    sampling never sits alone on the critical path: today's first launch (level 1 + state-0 search, 193 us at batch 64 of
+    1024 points: 183 us of sampling hiding a 64 us search) disappears, and every level rides beside searches of the
+    CURRENT batch, which exist anyway.  Two sets of buffers: `nxt` is written during the pass, `cur` = a copy of it taken
+    by the next pass's first node (one ~10 MB device copy), read by that pass's forward and backward.  Start indices are
+    drawn a step ahead in the reference's order; results are bit-identical to the in-pass chain
+    (tests/test_gpu_prefetch.py)."""
+
+    def __init__(self):
+        self.spec = None
+        self.enabled = True
+        self.ready = False           # `nxt` holds the geometry of the batch the next forward pass will see
+        self.next_xyz = None
+        self.cur = self.nxt = None
+        self.starts = None
+
+    class _Set:
+        pass
+
+    def supported(self):
+        (B, N, C), npoints, k = self.spec
+        return (C == 3 and 128 < N <= 2048 and 1 <= len(npoints) <= 8 and k <= 8 and
+                all(b <= a for a, b in zip((N,) + tuple(npoints), npoints)))
+
+    def allocate(self, device):
+        (B, N, _), npoints, k = self.spec
+        self.next_xyz = torch.zeros(B, N, 3, dtype=torch.float32, device=device)
+        parts = []                                        # (name, index, shape, dtype)
+        for i, s_ in enumerate(npoints):
+            parts.append(("fps_idx", i, (B, s_), torch.int64))
+            parts.append(("fps_xyz", i, (B, s_, 3), torch.float32))
+        parts.append(("knn0_dist", 0, (B, N, k), torch.float32))
+        parts.append(("knn0_idx", 0, (B, N, k), torch.int64))
+        offs, off = [], 0
+        for _, _, shape, dt in parts:
+            offs.append(off)
+            n = 1
+            for d in shape:
+                n *= d
+            off += (n * (8 if dt == torch.int64 else 4) + 255) // 256 * 256
+        sets = []
+        for _ in range(2):
+            flat = torch.zeros(off, dtype=torch.uint8, device=device)
+            st = GeometryPipeline._Set()
+            st.flat, st.fps_idx, st.fps_xyz = flat, [None] * len(npoints), [None] * len(npoints)
+            for (name, i, shape, dt), o in zip(parts, offs):
+                n = 1
+                for d in shape:
+                    n *= d
+                v = flat[o:o + n * (8 if dt == torch.int64 else 4)].view(dt).view(*shape)
+                if name == "fps_idx":
+                    st.fps_idx[i] = v
+                elif name == "fps_xyz":
+                    st.fps_xyz[i] = v
+                else:
+                    setattr(st, name, v)
+            sets.append(st)
+        self.cur, self.nxt = sets
+
+    def _draw_starts(self, device):
+        (B, N, _), npoints, _ = self.spec
+        return [_fps_start(B, n, device) for n in (N,) + tuple(npoints[:-1])]
+
+    def attach(self, chain):
+        """First thing of a forward pass: what the previous pass computed becomes this pass's geometry, the start indices
+        of the levels this pass will compute for the next batch are drawn (or fed)."""
+        (B, N, _), npoints, k = self.spec
+        self.cur.flat.copy_(self.nxt.flat)
+        g0 = chain.levels[0]
+        g0.dist, g0.idx = self.cur.knn0_dist, self.cur.knn0_idx
+        for i in range(len(npoints)):
+            g = _GeoLevel()
+            g.xyz, g.fps_idx, g.chain, g.i = self.cur.fps_xyz[i], self.cur.fps_idx[i], chain, i + 1
+            chain.levels[i + 1] = g
+        chain.pipe = self
+        self.starts = self._draw_starts(g0.xyz.device)
+
+    def level_launch(self, chain, i, base, xyz_i, k_feat, feature, query):
+        """State i's searches for the current batch + level i of the next batch's chain (+ its state-0 search at i = 1)."""
+        (B, N, _), npoints, k = self.spec
+        src = self.next_xyz if i == 1 else self.nxt.fps_xyz[i - 2]
+        # the next batch's state-0 search needs its coordinates only, so any launch could carry it: state 1's measured
+        # best (3.511 ms per cls-fp32 step against 3.535 in state 2's launch, 3.560 for the in-pass chain)
+        carrier = 2 if (len(npoints) >= 2 and PIPELINE_KNN0_LEVEL == 2) else 1
+        extra = (self.next_xyz, self.next_xyz, k, self.nxt.knn0_dist, self.nxt.knn0_idx) if i == carrier else None
+        return geo_level(src, npoints[i - 1], self.starts[i - 1], self.nxt.fps_idx[i - 1], self.nxt.fps_xyz[i - 1], chain.k,
+                         base, xyz_i, extra, k_feat, feature, query)
+
+    def riders(self):
+        return None                     # nothing rides in the weight-gradient launches in this form
+
+    def compute_now(self, xyz):
+        """The chain and the state-0 search of `xyz` [B,N,3] into `nxt` with the stand-alone entry points: the first batch
+        of a run, and any batch that was not announced a step ahead."""
+        (B, N, _), npoints, k = self.spec
+        xyz = _f32(xyz.detach())
+        starts = self._draw_starts(xyz.device)
+        cur = xyz
+        with torch.no_grad():
+            for i, s_ in enumerate(npoints):
+                idx, x = farthest_point_sample(cur, s_, start_idx=starts[i], return_xyz=True)
+                self.nxt.fps_idx[i].copy_(idx)
+                self.nxt.fps_xyz[i].copy_(x)
+                cur = self.nxt.fps_xyz[i]
+            clear_knn_memo()
+            d, j = knn_point(k, xyz, xyz)
+            self.nxt.knn0_dist.copy_(d)
+            self.nxt.knn0_idx.copy_(j)
+            clear_knn_memo()
         self.ready = True
 
 

@@ -136,7 +136,11 @@ class GraphedTrainStep:
         # head of the next step's forward pass.  step(*batch, next_batch=...) announces the next batch; a batch that was
         # not announced gets its geometry computed on the spot (correct, not hidden).  coords_of(batch) -> [B,3,N]
         # channel-first coordinates of a batch (default: the first three channels of batch[0], as both models read).
-        self.prefetch = ops.GeometryPrefetch() if prefetch_geometry else None
+        # prefetch_geometry = True / "searches": the next batch's chain rides in THIS batch's search launches
+        # (ops.GeometryPipeline); "riders": in the closing weight-gradient launches (ops.GeometryPrefetch, slower)
+        self.prefetch = None
+        if prefetch_geometry:
+            self.prefetch = ops.GeometryPrefetch() if prefetch_geometry == "riders" else ops.GeometryPipeline()
         self.coords_of = coords_of or (lambda batch: batch[0][:, :3])
         self._announced = None                   # (tensor, version) of the batch whose geometry the buffers hold
         # (the prefetch object is installed only while one of THIS step's passes runs, _fwd_bwd: any other forward of

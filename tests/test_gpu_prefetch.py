@@ -93,9 +93,12 @@ def test_fused_searches_without_sampling(ops):
         assert torch.equal(ix, i0) and torch.equal(dx, d0) and torch.equal(jf, i1) and torch.equal(df, d1)
 
 
-def test_prefetched_step_equals_in_pass_chain(ops, monkeypatch):
-    """GraphedTrainStep(prefetch_geometry=True) alternating between two distinct batches, each announced a step ahead,
-    against the plain step (chain inside the forward pass) on the same batches: same losses and same gradients.  (Fixed
+@pytest.mark.parametrize("form", [True, "riders"])
+def test_prefetched_step_equals_in_pass_chain(ops, monkeypatch, form):
+    """GraphedTrainStep(prefetch_geometry=True: the next batch's chain carried by this batch's search launches,
+    ops.GeometryPipeline; "riders": by the closing weight-gradient launches, ops.GeometryPrefetch) alternating between
+    distinct batches, each announced a step ahead, against the plain step (chain inside the forward pass) on the same
+    batches: same losses and same gradients.  (Fixed
     parameters -- lr = 0 -- bit-reproducible BatchNorm statistics and sampling starts that depend on the level only, so
     both runs see identical inputs.)  An unannounced batch still gets the right geometry (computed on the spot)."""
     from mpa_amd.models.repsurf.repsurf_ssg_umb import Model, SmoothClsLoss
@@ -113,7 +116,9 @@ def test_prefetched_step_equals_in_pass_chain(ops, monkeypatch):
             model = fill_state(Model(Namespace(num_point=N, return_dist=True, cuda_ops=True, num_class=40)), seed=1).cuda().train()
             model.drop1.p = model.drop2.p = 0.0
             step = GraphedTrainStep(model, SmoothClsLoss(), batches[0], lr=0.0, prefetch_geometry=prefetch)
-            assert (step.prefetch is not None) == prefetch
+            assert (step.prefetch is not None) == bool(prefetch)
+            if prefetch:
+                assert isinstance(step.prefetch, ops.GeometryPrefetch if prefetch == "riders" else ops.GeometryPipeline)
             out = []
             try:
                 order = [0, 1, 0, 2, 2, 1]
@@ -128,7 +133,7 @@ def test_prefetched_step_equals_in_pass_chain(ops, monkeypatch):
                 step.close()
             return out
 
-        ref, got = run(False), run(True)
+        ref, got = run(False), run(form)
         for t, ((l0, g0), (l1, g1)) in enumerate(zip(ref, got)):
             assert abs(l0 - l1) < 1e-6, (t, l0, l1)
             assert g0.keys() == g1.keys()
