@@ -6,6 +6,7 @@
 #define MPA_KNN_BODIES_ONLY
 #include "knn.hip"
 #include "fps_body.h"
+#include <cstdlib>
 
 namespace {
 
@@ -49,8 +50,8 @@ __global__ __launch_bounds__(256) void fps_knn2_kernel(const float *__restrict__
         return;
     }
     bid -= B;
-    // (the many short coordinate-search workgroups first, the long feature-search workgroups last: the other order was
-    // measured slower, 3.535 against 3.511 ms per classification step in the cross-step pipeline)
+    // (short coordinate-search workgroups first, the long feature-search workgroups last: the other order measured
+    // slower in both forms of the carrying launch, 3.535 / 3.470 against 3.511 / 3.452 ms per classification step)
     if (bid < x.blocks) {
         fused_xyz_search(x, bid, lds);
         return;
@@ -393,6 +394,15 @@ extern "C" int mpa_geo_level_f32(const float *fps_xyz, int B, int fps_N, int fps
     z.base = xyz2_base; z.query = xyz2_query; z.norms = nullptr; z.dist = xyz2_dist; z.idx = xyz2_idx;
     z.N = zN; z.S = zS; z.K = zK; z.qb = xyz2_base ? mpa_ceil_div(zS, 32) : 1; z.blocks = xyz2_base ? z.qb * B : 0;
     hipStream_t st = (hipStream_t)stream;
+    static const int carry_qg = getenv("MPA_CARRY_QG") ? atoi(getenv("MPA_CARRY_QG")) : 1;
+    if (C == 64 && feat_norms != nullptr && fB > 0 && xyz2_base != nullptr && carry_qg == 1) {
+        // the launch that carries a whole sampling level of the next batch beside a second coordinate search (the
+        // cross-step pipeline's state-1 launch): ONE query group per workgroup with the norms given -- shorter workgroups
+        // and 48 KiB of LDS / fewer registers (three workgroups per CU), so the feature search packs around the B
+        // sampling workgroups instead of leaving its last B workgroups to wait for their slots (324 us with two groups)
+        y.qb = mpa_ceil_div(S, 32); y.blocks = y.qb * B;
+        return launch_fused_p<64, 1, true>(P, fps_xyz, fB, fps_N, fps_S, start_idx, fps_idx, fps_out_xyz, x, y, z, st);
+    }
     if (C == 64 && feat_norms != nullptr) {                      // two query groups per workgroup (needs the norms)
         y.qb = mpa_ceil_div(S, 64); y.blocks = y.qb * B;
         return launch_fused_p<64, 2, true>(P, fps_xyz, fB, fps_N, fps_S, start_idx, fps_idx, fps_out_xyz, x, y, z, st);
