@@ -80,7 +80,7 @@ int mpa_knn_f32(const float *base, const float *query, int B, int N, int S, int 
  * xyz_base = NULL to skip) and its feature-space search (feat_*: as mpa_knn_f32 / mpa_knn_norms_f32, feat_norms optional)
  * in ONE launch: the sampling keeps one workgroup per cloud busy for fps_S dependent iterations, the searches use the
  * rest of the chip.  Results are those of the separate entry points bit for bit.  MPA_EUNSUPPORTED for shapes outside
- * the instantiated set (fps_N in 129..2048, K <= 8, C in {64, 128}, 16-byte aligned rows): use the separate calls. */
+ * the instantiated set (fps_N in 129..4096, K <= 8, C in {64, 128}, 16-byte aligned rows): use the separate calls. */
 int mpa_fps_knn_feat_f32(const float *fps_xyz, int B, int fps_N, int fps_S, const int64_t *start_idx,
                          int64_t *fps_idx, float *fps_out_xyz, const float *xyz_base, const float *xyz_query,
                          int xN, int xS, int xK, float *xyz_dist, int64_t *xyz_idx, const float *feat_base,

@@ -114,7 +114,8 @@ int launch_fused_p(int P, const float *fxyz, int B, int fN, int fS, const int64_
     case 1: return launch_fused<1, CT, QG, GN>(fxyz, B, fN, fS, start, f_idx, f_out_xyz, x, y, z, st);
     case 2: return launch_fused<2, CT, QG, GN>(fxyz, B, fN, fS, start, f_idx, f_out_xyz, x, y, z, st);
     case 4: return launch_fused<4, CT, QG, GN>(fxyz, B, fN, fS, start, f_idx, f_out_xyz, x, y, z, st);
-    default: return launch_fused<8, CT, QG, GN>(fxyz, B, fN, fS, start, f_idx, f_out_xyz, x, y, z, st);
+    case 8: return launch_fused<8, CT, QG, GN>(fxyz, B, fN, fS, start, f_idx, f_out_xyz, x, y, z, st);
+    default: return launch_fused<16, CT, QG, GN>(fxyz, B, fN, fS, start, f_idx, f_out_xyz, x, y, z, st);
     }
 }
 
@@ -379,11 +380,11 @@ extern "C" int mpa_geo_level_f32(const float *fps_xyz, int B, int fps_N, int fps
     if (!feat_base || !feat_query || !out_idx || B <= 0 || N <= 0 || S <= 0 || K <= 0) return MPA_EINVAL;
     if (sample && (!start_idx || !fps_idx || fps_N <= 0 || fps_S <= 0)) return MPA_EINVAL;
     if (xyz_base && (!xyz_query || !xyz_idx || xN <= 0 || xS <= 0 || xK <= 0)) return MPA_EINVAL;
-    // the instantiated combinations: FPS of 129..2048 points, K <= 8, feature rows of 64 / 128 floats, 16-byte aligned
-    if (K > 8 || K > N || (xyz_base && (xK > 8 || xK > xN)) || (sample && (fps_N <= 128 || fps_N > 2048)) ||
+    // the instantiated combinations: FPS of 129..4096 points, K <= 8, feature rows of 64 / 128 floats, 16-byte aligned
+    if (K > 8 || K > N || (xyz_base && (xK > 8 || xK > xN)) || (sample && (fps_N <= 128 || fps_N > 4096)) ||
         (C != 64 && C != 128) || ((((uintptr_t)feat_base | (uintptr_t)feat_query | (uintptr_t)feat_norms) & 15) != 0))
         return MPA_EUNSUPPORTED;
-    const int P = !sample || fps_N <= 256 ? 1 : (fps_N <= 512 ? 2 : (fps_N <= 1024 ? 4 : 8));
+    const int P = !sample || fps_N <= 256 ? 1 : (fps_N <= 512 ? 2 : (fps_N <= 1024 ? 4 : (fps_N <= 2048 ? 8 : 16)));
     const int fB = sample ? B : 0;               // sampling workgroups in front of the searches'
     FusedSearch x, y;
     x.base = xyz_base; x.query = xyz_query; x.norms = nullptr; x.dist = xyz_dist; x.idx = xyz_idx;

@@ -422,7 +422,7 @@ def geo_level(fps_src, npoint, start, fps_idx_out, fps_xyz_out, k_xyz, xyz_base,
     xb, xq = _f32(xyz_base.detach()), _f32(xyz_query.detach())
     xN, xS = xb.shape[1], xq.shape[1]
     coarse = extra is None and _coarse_ok(fN, xN, N, C, k_xyz, k_feat, fb, fq) and fN <= 256
-    regular = (FUSE_FPS_FEATURE_SEARCH and C in (64, 128) and k_feat <= 8 and k_xyz <= 8 and 128 < fN <= 2048
+    regular = (FUSE_FPS_FEATURE_SEARCH and C in (64, 128) and k_feat <= 8 and k_xyz <= 8 and 128 < fN <= 4096
                and fb.data_ptr() % 16 == 0 and fq.data_ptr() % 16 == 0 and (extra is None or extra[2] <= 8))
     if not (coarse or regular):
         idx, x = farthest_point_sample(fin, npoint, start_idx=start, return_xyz=True)
@@ -549,7 +549,7 @@ def fps_knn_fused(fps_in, npoint, k_xyz, xyz_base, xyz_query, k_feat, feat_base,
     if fps_in.shape[2] == 3 and _coarse_ok(fN, None if xyz_base is None else xyz_base.shape[1], N, C,
                                            None if xyz_base is None else k_xyz, k_feat, fb, fq):
         return _coarse_level(fps_in, npoint, start_idx, k_xyz, xyz_base, xyz_query, k_feat, fb, fq)
-    ok = (FUSE_FPS_FEATURE_SEARCH and C in (64, 128) and k_feat <= 8 and 128 < fN <= 2048 and fps_in.shape[2] == 3
+    ok = (FUSE_FPS_FEATURE_SEARCH and C in (64, 128) and k_feat <= 8 and 128 < fN <= 4096 and fps_in.shape[2] == 3
           and fb.data_ptr() % 16 == 0 and fq.data_ptr() % 16 == 0 and (xyz_base is None or k_xyz <= 8))
     if not ok:
         if xyz_base is not None:
@@ -790,7 +790,7 @@ class GeometryPipeline:
 
     def supported(self):
         (B, N, C), npoints, k = self.spec
-        return (C == 3 and 128 < N <= 2048 and 1 <= len(npoints) <= 8 and k <= 8 and
+        return (C == 3 and 128 < N <= 4096 and 1 <= len(npoints) <= 8 and k <= 8 and
                 all(b <= a for a, b in zip((N,) + tuple(npoints), npoints)))
 
     def allocate(self, device):
