@@ -839,6 +839,9 @@ class GeometryPipeline:
         self.cur.flat.copy_(self.nxt.flat)
         g0 = chain.levels[0]
         g0.dist, g0.idx = self.cur.knn0_dist, self.cur.knn0_idx
+        # a decoder that searches the input cloud in itself again (part-seg, S3DIS, completion) finds this result
+        xb = _f32(g0.xyz.detach().float())
+        _memo_put(xb, xb, k, g0.dist, g0.idx)
         for i in range(len(npoints)):
             g = _GeoLevel()
             g.xyz, g.fps_idx, g.chain, g.i = self.cur.fps_xyz[i], self.cur.fps_idx[i], chain, i + 1
