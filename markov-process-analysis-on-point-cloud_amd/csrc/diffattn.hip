@@ -563,41 +563,82 @@ __global__ __launch_bounds__(TPB) void diffattn_xyz_fwd_kernel(
     const float *__restrict__ xyz, const float *__restrict__ center, const int64_t *__restrict__ idx,
     const float *__restrict__ Wq, const float *__restrict__ bq, const float *__restrict__ Wk,
     const float *__restrict__ bk, const float *__restrict__ Wv, const float *__restrict__ bv, int N, int S, int K,
-    int C, float alpha, long long npoints, TF *__restrict__ ctx, uint8_t *__restrict__ argk)
+    int C, int bx, float alpha, long long npoints, TF *__restrict__ ctx, uint8_t *__restrict__ argk)
 {
     const int k_ = K_ > 0 ? K_ : K;
-    const int c = blockIdx.y * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const float wq0 = Wq[c * 3], wq1 = Wq[c * 3 + 1], wq2 = Wq[c * 3 + 2], bqc = bq[c];
-    const float wk0 = Wk[c * 3], wk1 = Wk[c * 3 + 1], wk2 = Wk[c * 3 + 2], bkc = bk[c];
-    const float wv0 = Wv[c * 3], wv1 = Wv[c * 3 + 1], wv2 = Wv[c * 3 + 2], bvc = bv[c];
-    for (long long p = blockIdx.x; p < npoints; p += gridDim.x) {
-        int b = (int)(p / S);
-        const float cx = center[p * 3], cy = center[p * 3 + 1], cz = center[p * 3 + 2];
-        const float qv = fmaf(wq2, cz, fmaf(wq1, cy, fmaf(wq0, cx, bqc)));
-        const int64_t *nb = idx + p * k_;
-        float e[K_ > 0 ? K_ : KMAX], v[K_ > 0 ? K_ : KMAX], a[K_ > 0 ? K_ : KMAX];
+    // bx channel lanes (a multiple of 64: a wave shares its point) x PW point lanes per workgroup, as in the backward kernel
+    const int pw = __builtin_amdgcn_readfirstlane(threadIdx.x / bx), PW = blockDim.x / bx;
+    const int c = blockIdx.y * bx + threadIdx.x % bx;
+    const bool live = c < C;                 // (every lane stays: lanes 0..3*KK+2 of each wave stage the point's operands)
+    const int cc = live ? c : C - 1;
+    const float wq0 = Wq[cc * 3], wq1 = Wq[cc * 3 + 1], wq2 = Wq[cc * 3 + 2], bqc = bq[cc];
+    const float wk0 = Wk[cc * 3], wk1 = Wk[cc * 3 + 1], wk2 = Wk[cc * 3 + 2], bkc = bk[cc];
+    const float wv0 = Wv[cc * 3], wv1 = Wv[cc * 3 + 1], wv2 = Wv[cc * 3 + 2], bvc = bv[cc];
+    // centre + neighbour coordinates of a point: staged by one vector load per hop (lane 3j+c = component c of neighbour
+    // j, lanes 3*KK..3*KK+2 = centre), one point ahead, and handed to the wave with v_readlane -- see the backward kernel
+    constexpr int KK = K_ > 0 ? K_ : KMAX;
+    const int lane = threadIdx.x & 63;
+    const int sj = lane / 3, sc = lane - 3 * sj;
+    const bool nb_lane = lane < 3 * k_, c_lane = lane >= 3 * KK && lane < 3 * KK + 3;
+    auto hop1 = [&](long long pp) -> long long { return nb_lane ? (long long)idx[pp * k_ + sj] : 0ll; };
+    auto hop2 = [&](long long pp, int bb, long long vi) -> float {
+        const float *src = nb_lane ? xyz + ((long long)bb * N + mpa_clamp_idx(vi, N)) * 3 + sc
+                                   : center + pp * 3 + (c_lane ? lane - 3 * KK : 0);
+        return (nb_lane || c_lane) ? *src : 0.f;
+    };
+    const long long stride = (long long)gridDim.x * PW;
+    long long p = (long long)blockIdx.x * PW + pw;
+    int b = (int)(p / S), s = (int)(p - (long long)b * S);
+    const int db = (int)(stride / S), ds = (int)(stride - (long long)db * S);
+    float vx = 0.f;
+    if (p < npoints) vx = hop2(p, b, hop1(p));
+    while (p < npoints) {
+        const long long pn = p + stride;
+        int bn = b + db, sn = s + ds;
+        if (sn >= S) { sn -= S; ++bn; }
+        const bool more = pn < npoints;
+        const long long pq = more ? pn : p;
+        const int bq = more ? bn : b;
+        const int vxi = __float_as_int(vx);
+        const float cx = __int_as_float(__builtin_amdgcn_readlane(vxi, 3 * KK));
+        const float cy = __int_as_float(__builtin_amdgcn_readlane(vxi, 3 * KK + 1));
+        const float cz = __int_as_float(__builtin_amdgcn_readlane(vxi, 3 * KK + 2));
+        float rx[KK], ry[KK], rz[KK];
 #pragma unroll
-        for (int j = 0; j < (K_ > 0 ? K_ : KMAX); ++j)
+        for (int j = 0; j < KK; ++j) {
+            rx[j] = __int_as_float(__builtin_amdgcn_readlane(vxi, 3 * j)) - cx;
+            ry[j] = __int_as_float(__builtin_amdgcn_readlane(vxi, 3 * j + 1)) - cy;
+            rz[j] = __int_as_float(__builtin_amdgcn_readlane(vxi, 3 * j + 2)) - cz;
+        }
+        const long long vi2 = hop1(pq);
+        __builtin_amdgcn_sched_barrier(0);
+        const float qv = fmaf(wq2, cz, fmaf(wq1, cy, fmaf(wq0, cx, bqc)));
+        float e[KK], v[KK], a[KK];
+#pragma unroll
+        for (int j = 0; j < KK; ++j)
             if (j < k_) {
-                const float *x = xyz + ((long long)b * N + mpa_clamp_idx(nb[j], N)) * 3;
-                float rx = x[0] - cx, ry = x[1] - cy, rz = x[2] - cz;
-                float kj = fmaf(wk2, rz, fmaf(wk1, ry, fmaf(wk0, rx, bkc)));
-                v[j] = fmaf(wv2, rz, fmaf(wv1, ry, fmaf(wv0, rx, bvc)));
+                float kj = fmaf(wk2, rz[j], fmaf(wk1, ry[j], fmaf(wk0, rx[j], bkc)));
+                v[j] = fmaf(wv2, rz[j], fmaf(wv1, ry[j], fmaf(wv0, rx[j], bvc)));
                 e[j] = (qv - kj) * alpha;
             }
+        __builtin_amdgcn_sched_barrier(0);
+        vx = hop2(pq, bq, vi2);
+        __builtin_amdgcn_sched_barrier(0);
         float o;
         softmax_offset<K_>(e, k_, a, o);
         float best = (a[0] - o) * v[0];
         int bj = 0;
 #pragma unroll
-        for (int j = 1; j < (K_ > 0 ? K_ : KMAX); ++j)
+        for (int j = 1; j < KK; ++j)
             if (j < k_) {
                 float t = (a[j] - o) * v[j];
                 if (t > best) { best = t; bj = j; }
             }
-        mpa_st1<TF>(ctx + p * C + c, best);
-        argk[p * C + c] = (uint8_t)bj;
+        if (live) {
+            mpa_st1<TF>(ctx + p * C + c, best);
+            argk[p * C + c] = (uint8_t)bj;
+        }
+        p = pn; b = bn; s = sn;
     }
 }
 
@@ -625,21 +666,64 @@ __global__ __launch_bounds__(BWD_TPB) void diffattn_xyz_bwd_kernel(
     const float wk0 = Wk[cc * 3], wk1 = Wk[cc * 3 + 1], wk2 = Wk[cc * 3 + 2], bkc = bk[cc];
     const float wv0 = Wv[cc * 3], wv1 = Wv[cc * 3 + 1], wv2 = Wv[cc * 3 + 2], bvc = bv[cc];
     float aq[4] = {0, 0, 0, 0}, ak[4] = {0, 0, 0, 0}, av[4] = {0, 0, 0, 0};   // (dW[0..2], db)
-    for (long long p = (long long)blockIdx.x * PW + pw; p < npoints; p += (long long)gridDim.x * PW) {
-        int b = (int)(p / S);
-        const float cx = center[p * 3], cy = center[p * 3 + 1], cz = center[p * 3 + 2];
+    // The point's centre, neighbour indices and neighbour coordinates are wave-uniform and a two-hop dependent chain
+    // (indices, then rows).  As scalar loads they were ~20 scalar-cache misses per point and wave, and that miss path,
+    // not the VALU, bounded the kernel (2.5x its instruction count).  Now ONE vector load per hop stages them: lane
+    // 3j+c holds component c of neighbour j, lanes 3*KK..3*KK+2 the centre; v_readlane hands them to the whole wave.
+    // Both hops run ONE POINT AHEAD (indices before the current point's softmax, rows after it).  The cloud of a
+    // point (p / S, a 64-bit scalar division: ~150 SALU instructions) is carried along incrementally.
+    constexpr int KK = K_ > 0 ? K_ : KMAX;
+    const long long stride = (long long)gridDim.x * PW;
+    long long p = (long long)blockIdx.x * PW + pw;
+    int b = (int)(p / S), s = (int)(p - (long long)b * S);
+    const int db = (int)(stride / S), ds = (int)(stride - (long long)db * S);
+    const int lane = threadIdx.x & 63;
+    const int sj = lane / 3, sc = lane - 3 * sj;
+    const bool nb_lane = lane < 3 * k_, c_lane = lane >= 3 * KK && lane < 3 * KK + 3;
+    auto hop1 = [&](long long pp) -> long long { return nb_lane ? (long long)idx[pp * k_ + sj] : 0ll; };
+    auto hop2 = [&](long long pp, int bb, long long vi) -> float {
+        const float *src = nb_lane ? xyz + ((long long)bb * N + mpa_clamp_idx(vi, N)) * 3 + sc
+                                   : center + pp * 3 + (c_lane ? lane - 3 * KK : 0);
+        return (nb_lane || c_lane) ? *src : 0.f;
+    };
+    float vx = 0.f;
+    if (p < npoints) vx = hop2(p, b, hop1(p));
+    int ks_n = 0;
+    float g_n = 0.f;
+    if (p < npoints) {
+        ks_n = argk[p * C + cc];
+        g_n = mpa_ld1<TF>(gctx + p * C + cc);
+    }
+    while (p < npoints) {
+        const long long pn = p + stride;
+        int bn = b + db, sn = s + ds;
+        if (sn >= S) { sn -= S; ++bn; }
+        const bool more = pn < npoints;
+        const long long pq = more ? pn : p;
+        const int bq = more ? bn : b;
+        const int vxi = __float_as_int(vx);
+        const float cx = __int_as_float(__builtin_amdgcn_readlane(vxi, 3 * KK));
+        const float cy = __int_as_float(__builtin_amdgcn_readlane(vxi, 3 * KK + 1));
+        const float cz = __int_as_float(__builtin_amdgcn_readlane(vxi, 3 * KK + 2));
+        float rx[KK], ry[KK], rz[KK];
+#pragma unroll
+        for (int j = 0; j < KK; ++j) {
+            rx[j] = __int_as_float(__builtin_amdgcn_readlane(vxi, 3 * j)) - cx;
+            ry[j] = __int_as_float(__builtin_amdgcn_readlane(vxi, 3 * j + 1)) - cy;
+            rz[j] = __int_as_float(__builtin_amdgcn_readlane(vxi, 3 * j + 2)) - cz;
+        }
+        const int ks = ks_n;
+        const float g = g_n;
+        ks_n = argk[pq * C + cc];                   // (the lane's own two loads, also one point ahead)
+        g_n = mpa_ld1<TF>(gctx + pq * C + cc);
+        const long long vi2 = hop1(pq);             // first hop for the next point
+        __builtin_amdgcn_sched_barrier(0);
         const float qv = fmaf(wq2, cz, fmaf(wq1, cy, fmaf(wq0, cx, bqc)));
-        const int64_t *nb = idx + p * k_;
-        const int ks = argk[p * C + cc];
-        const float g = mpa_ld1<TF>(gctx + p * C + cc);
-        float e[K_ > 0 ? K_ : KMAX], a[K_ > 0 ? K_ : KMAX];
-        float rx[K_ > 0 ? K_ : KMAX], ry[K_ > 0 ? K_ : KMAX], rz[K_ > 0 ? K_ : KMAX];
+        float e[KK], a[KK];
         float vstar = 0.f, sx = 0.f, sy = 0.f, sz = 0.f;
 #pragma unroll
-        for (int j = 0; j < (K_ > 0 ? K_ : KMAX); ++j)
+        for (int j = 0; j < KK; ++j)
             if (j < k_) {
-                const float *x = xyz + ((long long)b * N + mpa_clamp_idx(nb[j], N)) * 3;
-                rx[j] = x[0] - cx; ry[j] = x[1] - cy; rz[j] = x[2] - cz;
                 float kj = fmaf(wk2, rz[j], fmaf(wk1, ry[j], fmaf(wk0, rx[j], bkc)));
                 e[j] = (qv - kj) * alpha;
                 if (j == ks) {
@@ -649,15 +733,18 @@ __global__ __launch_bounds__(BWD_TPB) void diffattn_xyz_bwd_kernel(
             }
         float o;
         softmax_offset<K_>(e, k_, a, o);
+        __builtin_amdgcn_sched_barrier(0);
+        vx = hop2(pq, bq, vi2);                     // second hop for the next point
+        __builtin_amdgcn_sched_barrier(0);
         float astar = 0.f;
 #pragma unroll
-        for (int j = 0; j < (K_ > 0 ? K_ : KMAX); ++j)
+        for (int j = 0; j < KK; ++j)
             if (j < k_ && j == ks) astar = a[j];
         const float h = g * vstar;
         const float common = -1.0f - astar + o;
         float dq = 0.f;
 #pragma unroll
-        for (int j = 0; j < (K_ > 0 ? K_ : KMAX); ++j)
+        for (int j = 0; j < KK; ++j)
             if (j < k_) {
                 float de = a[j] * h * ((j == ks ? 1.0f : 0.0f) + common);
                 dq += de;
@@ -669,6 +756,7 @@ __global__ __launch_bounds__(BWD_TPB) void diffattn_xyz_bwd_kernel(
         aq[0] = fmaf(dq, cx, aq[0]); aq[1] = fmaf(dq, cy, aq[1]); aq[2] = fmaf(dq, cz, aq[2]); aq[3] += dq;
         const float dv = g * (astar - o);
         av[0] = fmaf(dv, sx, av[0]); av[1] = fmaf(dv, sy, av[1]); av[2] = fmaf(dv, sz, av[2]); av[3] += dv;
+        p = pn; b = bn; s = sn;
     }
     // block reduction over the PW point lanes through LDS with plain stores (LDS float atomics retire
     // ~1 lane per 2.5 clocks: 12 of them per thread were a quarter of this kernel), then one global
@@ -921,16 +1009,19 @@ static int diffattn_xyz_fwd_any(const float *xyz, const float *center, const int
         return MPA_EINVAL;
     if (K > KMAX) return MPA_EUNSUPPORTED;
     long long np = (long long)B * S;
-    int bx = C >= TPB ? TPB : ((C + 63) / 64) * 64;
-    dim3 grid((unsigned)(np > 8192 ? 8192 : np), mpa_ceil_div(C, bx));
+    const int bx = C > 128 ? 256 : (C > 64 ? 128 : 64);      // channel lanes: a divisor of TPB
+    const int pw = TPB / bx;
+    static const int cap = getenv("MPA_XYZ_FWD_BLOCKS") ? atoi(getenv("MPA_XYZ_FWD_BLOCKS")) : 2048;
+    const long long gx = (np + pw - 1) / pw;
+    dim3 grid((unsigned)(gx > cap ? cap : gx), mpa_ceil_div(C, bx));
     float alpha = 1.0f / sqrtf((float)C);
     hipStream_t st = (hipStream_t)stream;
     if (K == 8)
-        hipLaunchKernelGGL((diffattn_xyz_fwd_kernel<8, TF>), grid, dim3(bx), 0, st, xyz, center, idx, Wq, bq, Wk, bk, Wv, bv,
-                           N, S, K, C, alpha, np, ctx, argk);
+        hipLaunchKernelGGL((diffattn_xyz_fwd_kernel<8, TF>), grid, dim3(TPB), 0, st, xyz, center, idx, Wq, bq, Wk, bk, Wv, bv,
+                           N, S, K, C, bx, alpha, np, ctx, argk);
     else
-        hipLaunchKernelGGL((diffattn_xyz_fwd_kernel<0, TF>), grid, dim3(bx), 0, st, xyz, center, idx, Wq, bq, Wk, bk, Wv, bv,
-                           N, S, K, C, alpha, np, ctx, argk);
+        hipLaunchKernelGGL((diffattn_xyz_fwd_kernel<0, TF>), grid, dim3(TPB), 0, st, xyz, center, idx, Wq, bq, Wk, bk, Wv, bv,
+                           N, S, K, C, bx, alpha, np, ctx, argk);
     MPA_LAUNCH_CHECK();
     return MPA_OK;
 }
@@ -967,7 +1058,8 @@ static int diffattn_xyz_bwd_any(const float *xyz, const float *center, const int
     int bx = C > 128 ? 256 : (C > 64 ? 128 : 64);           // channel lanes: a divisor of 1024
     const int pw = BWD_TPB / bx;
     long long gx = (np + pw - 1) / pw;
-    dim3 grid((unsigned)(gx > 512 ? 512 : gx), mpa_ceil_div(C, bx));
+    static const int cap = getenv("MPA_XYZ_BWD_BLOCKS") ? atoi(getenv("MPA_XYZ_BWD_BLOCKS")) : 256;
+    dim3 grid((unsigned)(gx > cap ? cap : gx), mpa_ceil_div(C, bx));
     float alpha = 1.0f / sqrtf((float)C);
     hipStream_t st = (hipStream_t)stream;
     if (K == 8)

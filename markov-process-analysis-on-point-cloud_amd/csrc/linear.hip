@@ -60,6 +60,7 @@ __device__ __forceinline__ void gemm_body(const int block_x, const int block_z, 
     constexpr int BUF = KS * (LDA + LDB);
     extern __shared__ float lds[];   // 2 * BUF floats = 4*64*64: reused by the final reduction
 #define SWZ(k) ((((k) >> 2) & 7) << 2)
+#define PIN() __builtin_amdgcn_sched_barrier(0)   // nothing moves across: requests stay in front of the multiply phase
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
@@ -246,28 +247,99 @@ __device__ __forceinline__ void gemm_body(const int block_x, const int block_z, 
             asum1 += a1;
         }
     };
+    // multiply(buf) with the operands of step t+1 read from LDS before step t's MFMAs are issued, and -- optionally -- the
+    // other register set written to `nbuf` a quarter at a time between the MFMA groups, so the LDS traffic of a slab runs
+    // under its MFMAs instead of in front of the barrier
+    auto store_quarter = [&](float *buf, const float4 (&ra)[4], const float4 (&rb)[4], int q) {
+        float *As = buf, *Bs = buf + KS * LDA;
+        const int i = tid + NT * q;
+        const int r = i >> 4, c = (i & 15) * 4;
+        if (!TA) {
+            float *d = As + c * LDA + (r ^ SWZ(c));
+            d[0] = ra[q].x; d[LDA] = ra[q].y; d[2 * LDA] = ra[q].z; d[3 * LDA] = ra[q].w;
+        } else {
+            *reinterpret_cast<float4 *>(As + r * LDA + (c ^ SWZ(r))) = ra[q];
+        }
+        if (TB) {
+            float *d = Bs + c * LDB + (r ^ SWZ(c));
+            d[0] = rb[q].x; d[LDB] = rb[q].y; d[2 * LDB] = rb[q].z; d[3 * LDB] = rb[q].w;
+        } else {
+            *reinterpret_cast<float4 *>(Bs + r * LDB + (c ^ SWZ(r))) = rb[q];
+        }
+    };
+    auto multiply_store = [&](const float *buf, float *nbuf, const float4 (&ra)[4], const float4 (&rb)[4], auto with_store) {
+        constexpr bool STORE = decltype(with_store)::value;
+        const float *As = buf + (wave * 16 + half) * LDA;
+        const float *Bs = buf + KS * LDA + (wave * 16 + half) * LDB;
+        float a0[2], a1[2], b0[2], b1[2];
+        auto fetch = [&](int t, int slot) {
+            const int cs = l31 ^ ((((wave << 2) + (t >> 1)) & 7) << 2);
+            a0[slot] = As[2 * t * LDA + cs]; a1[slot] = As[2 * t * LDA + 32 + cs];
+            b0[slot] = Bs[2 * t * LDB + cs]; b1[slot] = Bs[2 * t * LDB + 32 + cs];
+        };
+        fetch(0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int sl = t & 1;
+            if (t < 7) fetch(t + 1, sl ^ 1);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[sl], b0[sl], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[sl], b1[sl], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[sl], b0[sl], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[sl], b1[sl], acc[1][1], 0, 0, 0);
+            asum0 += a0[sl];
+            asum1 += a1[sl];
+            if (STORE && (t & 1)) store_quarter(nbuf, ra, rb, t >> 1);
+            if (t < 7) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // the two operand reads of step t+1
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                 // step t's MFMAs
+            if (STORE && (t & 1)) __builtin_amdgcn_sched_group_barrier(0x200, 4, 0);
+        }
+    };
     auto main_loop = [&](auto interior) {
+        constexpr bool INTERIOR = decltype(interior)::value;
+        if (INTERIOR && nslab >= 4) {
+            // Straight-line prologue, steady loop and tail: with nothing conditional between a request and its use the
+            // compiler's wait counts are exact (vmcnt(8): the older register set has landed, the newer is in flight).
+            // Behind a conditional request they were merged to vmcnt(0) at the loop head, which left a request less
+            // than one multiply phase to land instead of two.
+            load_slab(interior, 0, ra0, rb0);
+            load_slab(interior, 1, ra1, rb1);
+            store_slab(lds, ra0, rb0);
+            __syncthreads();
+            int s = 0;
+            for (; s + 3 < nslab; s += 2) {
+                load_slab(interior, s + 2, ra0, rb0);
+                PIN();
+                multiply_store(lds, lds + BUF, ra1, rb1, std::true_type{});
+                __syncthreads();
+                load_slab(interior, s + 3, ra1, rb1);
+                PIN();
+                multiply_store(lds + BUF, lds, ra0, rb0, std::true_type{});
+                __syncthreads();
+            }
+            if (nslab - s == 3) {
+                load_slab(interior, s + 2, ra0, rb0);
+                PIN();
+                multiply_store(lds, lds + BUF, ra1, rb1, std::true_type{});
+                __syncthreads();
+                multiply_store(lds + BUF, lds, ra0, rb0, std::true_type{});
+                __syncthreads();
+                multiply_store(lds, nullptr, ra0, rb0, std::false_type{});
+            } else {
+                multiply_store(lds, lds + BUF, ra1, rb1, std::true_type{});
+                __syncthreads();
+                multiply_store(lds + BUF, nullptr, ra0, rb0, std::false_type{});
+            }
+            __syncthreads();          // the epilogue reuses the slab buffers: every wave's operand reads are done
+            return;
+        }
         if (nslab > 0) {
             load_slab(interior, 0, ra0, rb0);
             if (nslab > 1) load_slab(interior, 1, ra1, rb1);
             store_slab(lds, ra0, rb0);
         }
         __syncthreads();
-        int s = 0;
-        // steady state (every load unconditional, so no value merges for the register allocator to
-        // resolve with copies that would wait on the loads): even slab s in buffer 0; set 1 holds
-        // slab s+1; set 0 is free
-        for (; s + 3 < nslab; s += 2) {
-            load_slab(interior, s + 2, ra0, rb0);
-            multiply(lds);
-            store_slab(lds + BUF, ra1, rb1);
-            __syncthreads();
-            load_slab(interior, s + 3, ra1, rb1);
-            multiply(lds + BUF);
-            store_slab(lds, ra0, rb0);
-            __syncthreads();
-        }
-        for (; s < nslab; s += 2) {                 // the last 1..3 slabs
+        for (int s = 0; s < nslab; s += 2) {        // short or ragged products: every step conditional
             if (s + 2 < nslab) load_slab(interior, s + 2, ra0, rb0);
             multiply(lds);
             if (s + 1 < nslab) store_slab(lds + BUF, ra1, rb1);

@@ -13,18 +13,20 @@ struct Shape { int M, N, K, tA, tB, stats; const char *what; };
 int main()
 {
     std::vector<Shape> shapes = {
-        {65536, 64, 64, 0, 1, 1, "la0 ffn fwd"},      {65536, 64, 3, 0, 1, 1, "la0 conv_res fwd"},
-        {65536, 128, 64, 0, 1, 0, "la1 kv fwd"},      {32768, 64, 64, 0, 1, 1, "la1 ffn fwd"},
-        {32768, 64, 128, 0, 1, 1, "la1 fc2 fwd"},     {16384, 256, 64, 0, 1, 0, "la3 kv fwd"},
-        {8192, 128, 128, 0, 1, 1, "la3 ffn fwd"},     {8192, 512, 128, 0, 1, 0, "la4 kv fwd"},
-        {4096, 256, 256, 0, 1, 1, "la4 ffn fwd"},     {4096, 1024, 256, 0, 1, 0, "la5 kv fwd"},
-        {2048, 512, 512, 0, 1, 1, "la5 ffn fwd"},     {2048, 512, 1024, 0, 1, 1, "la5 fc2 fwd"},
-        {2048, 1024, 512, 0, 1, 1, "conv4 fwd"},
-        {65536, 64, 64, 0, 0, 0, "la0 ffn dX"},       {65536, 64, 128, 0, 0, 0, "la1 kv dX"},
-        {4096, 256, 1024, 0, 0, 0, "la5 kv dX"},      {2048, 512, 1024, 0, 0, 0, "conv4 dX"},
-        {64, 64, 65536, 1, 0, 0, "la0 ffn dW"},       {128, 64, 65536, 1, 0, 0, "la1 kv dW"},
-        {64, 128, 32768, 1, 0, 0, "la1 fc2 dW"},      {1024, 256, 4096, 1, 0, 0, "la5 kv dW"},
-        {1024, 512, 2048, 1, 0, 0, "conv4 dW"},       {512, 512, 2048, 1, 0, 0, "la5 ffn dW"},
+        // the cls-fp32 step's tiled launches, by time (tools/gemm_tags.py)
+        {4096, 2048, 256, 0, 1, 0, "fan-out fwd"},    {4096, 256, 2048, 0, 0, 0, "fan-out dX"},
+        {65536, 64, 256, 0, 0, 0, "la1 dX"},          {65536, 256, 64, 0, 1, 0, "la1 fwd"},
+        {8192, 1024, 128, 0, 1, 0, "fan-out fwd"},    {2048, 512, 1024, 0, 1, 1, "fc fwd"},
+        {8192, 128, 1024, 0, 0, 0, "fan-out dX"},     {2048, 512, 1024, 0, 0, 0, "fc dX"},
+        {2048, 1024, 512, 0, 1, 1, "fc fwd"},         {2048, 1024, 512, 0, 0, 0, "fc dX"},
+        {8192, 128, 128, 0, 1, 1, "ffn fwd"},         {4096, 256, 128, 0, 1, 1, "ffn fwd"},
+        {2048, 256, 1024, 0, 0, 0, "dX"},             {4096, 256, 512, 0, 1, 1, "fwd"},
+        {32768, 64, 64, 0, 1, 1, "ffn fwd"},          {2048, 512, 512, 0, 1, 1, "fwd"},
+        {32768, 256, 64, 0, 1, 0, "fwd"},             {32768, 64, 256, 0, 0, 0, "dX"},
+        {8192, 128, 256, 0, 1, 1, "fwd"},             {16384, 512, 64, 0, 1, 0, "fwd"},
+        {16384, 64, 512, 0, 0, 0, "dX"},              {4096, 512, 256, 0, 0, 0, "dX"},
+        {64, 1024, 2048, 0, 1, 1, "head fwd"},        {64, 2048, 1024, 0, 0, 0, "head dX"},
+        {8192, 8192, 4096, 0, 1, 0, "large"},
     };
     size_t maxA = 0, maxB = 0, maxC = 0;
     for (auto &s : shapes) {
@@ -42,6 +44,7 @@ int main()
     hipMemset(bias, 0, 4096 * 4); hipMemset(st, 0, 1024 * 2 * 1024 * 4);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
+    double total = 0;
     for (auto &s : shapes) {
         int lda = s.tA ? s.M : s.K, ldb = s.tB ? s.K : s.N;
         auto run = [&]() {
@@ -62,6 +65,8 @@ int main()
         double fl = 2.0 * s.M * s.N * s.K, by = 4.0 * ((double)s.M * s.K + (double)s.N * s.K + (double)s.M * s.N);
         printf("%-18s M=%6d N=%5d K=%6d tA=%d tB=%d : %8.1f us  %6.1f TFLOP/s  %5.2f TB/s\n", s.what, s.M, s.N, s.K,
                s.tA, s.tB, us, fl / us / 1e6, by / us / 1e6);
+        if (s.M * (double)s.N * s.K < 1e11) total += us;
     }
+    printf("sum over the step's shapes: %.1f us\n", total);
     return 0;
 }

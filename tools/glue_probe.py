@@ -47,3 +47,15 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stac
 
 print(prof.key_averages(group_by_input_shape=True).table(sort_by="self_device_time_total", row_limit=90,
                                                           max_name_column_width=60, max_shapes_column_width=70))
+
+# per calling line: the ATen ops that launch device work
+import collections
+agg = collections.Counter()
+for ev in prof.events():
+    if not ev.name.startswith("aten::") or ev.self_device_time_total <= 0:
+        continue
+    stack = [s for s in (ev.stack or []) if "mpa_amd" in s or "markov" in s or "bench" in s]
+    agg[(ev.name, " <- ".join(s.split("/")[-1] for s in stack[:3]))] += 1
+print("\nATen launches by calling line (count per pass):")
+for (name, where), n in sorted(agg.items(), key=lambda kv: -kv[1]):
+    print("%3d  %-28s %s" % (n, name, where))
