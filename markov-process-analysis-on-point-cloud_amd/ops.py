@@ -105,6 +105,13 @@ def _f32(t):
     return t.contiguous()
 
 
+def _f32_pair(base, query):
+    """The fp32 rows the searches read, of `base` and `query` (bf16 features: their exact fp32 values).  A state searched
+    in itself (the decoder's blocks) is converted once."""
+    b = _f32(base.detach().float())
+    return b, (b if query is base else _f32(query.detach().float()))
+
+
 def _i64(t):
     return t.to(torch.int64).contiguous()
 
@@ -303,7 +310,7 @@ def knn_point(nsample, xyz, new_xyz):
     _dev(xyz, new_xyz)
     # bf16 features: the search runs on their exact fp32 values (distances and indices are always fp32 /
     # int64 work: the result is the reference's arithmetic applied to the rounded features)
-    base, query = _f32(xyz.detach().float()), _f32(new_xyz.detach().float())
+    base, query = _f32_pair(xyz, new_xyz)
     B, N, C = base.shape
     S = query.shape[1]
     if C == 3:
@@ -413,7 +420,7 @@ def geo_level(fps_src, npoint, start, fps_idx_out, fps_xyz_out, k_xyz, xyz_base,
     as one launch where the shapes allow (mpa_geo_level_f32 / mpa_coarse_level_f32), else as the separate entry points.
     -> ((dist, idx), (dist_f, idx_f)); every result equals the separate calls' bit for bit."""
     _dev(fps_src, xyz_base, feat_base)
-    fb, fq = _f32(feat_base.detach().float()), _f32(feat_query.detach().float())
+    fb, fq = _f32_pair(feat_base, feat_query)
     B, N, C = fb.shape
     S = fq.shape[1]
     fin = _f32(fps_src.detach())
@@ -507,7 +514,7 @@ def knn_xyz_and_feature(k_xyz, xyz_base, xyz_query, k_feat, feat_base, feat_quer
     shapes allow (the fused kernel of fps_knn_fused without sampling workgroups), else as two.
     -> ((dist, idx), (dist_f, idx_f)), bit-identical to the separate calls."""
     _dev(xyz_base, feat_base, feat_query)
-    fb, fq = _f32(feat_base.detach().float()), _f32(feat_query.detach().float())
+    fb, fq = _f32_pair(feat_base, feat_query)
     B, N, C = fb.shape
     S = fq.shape[1]
     if _coarse_ok(None, xyz_base.shape[1], N, C, k_xyz, k_feat, fb, fq):
@@ -542,7 +549,7 @@ def fps_knn_fused(fps_in, npoint, k_xyz, xyz_base, xyz_query, k_feat, feat_base,
     64 / 128 floats, k <= 8, 129..2048 points to sample from), otherwise as the separate launches.
     -> (fps_idx, fps_xyz, (dist, idx) | None, (dist_f, idx_f)); every result equals the separate calls' bit for bit."""
     _dev(fps_in, feat_base, feat_query)
-    fb, fq = _f32(feat_base.detach().float()), _f32(feat_query.detach().float())
+    fb, fq = _f32_pair(feat_base, feat_query)
     B, N, C = fb.shape
     S = fq.shape[1]
     fN = fps_in.shape[1]

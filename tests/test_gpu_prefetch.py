@@ -229,7 +229,10 @@ def test_pipelined_partseg_step_at_4096_points(ops, monkeypatch):
             return out
 
         for t, ((l0, g0), (l1, g1)) in enumerate(zip(run(False), run(True))):
-            assert abs(l0 - l1) < 1e-6, (t, l0, l1)
+            # (not bit for bit: `upsample` sums a fine point's contributors in the order the inverted table's atomic cursors
+            # listed them, so the first decoder stage already differs by ~1e-6 from run to run of the SAME step and the
+            # feature-space searches behind it amplify that -- tools/determinism_probe.py; losses agree to ~1e-5)
+            assert abs(l0 - l1) < 5e-5 * max(1.0, abs(l0)), (t, l0, l1)
             gmax = max(float(v.abs().max()) for v in g0.values())
             for n in g0:
                 err = float((g0[n] - g1[n]).norm() / g0[n].norm().clamp_min(1e-12))
