@@ -123,27 +123,38 @@ __global__ __launch_bounds__(TPB) void upsample_gather_kernel(const T *__restric
     const int *rp = rowptr + (size_t)b * (Nf + 1);
     const int beg = rp[n], end = rp[n + 1];
     const int *en = entries + (size_t)b * S * K;
-    const int64_t *kb = knn + (size_t)b * S * K;
     const T *pb = points + (size_t)b * S * C;
     for (int c = cl * V; c < C; c += lanes_per_row * V) {
         float acc[V];
 #pragma unroll
         for (int u = 0; u < V; ++u) acc[u] = 0.f;
         float div = 0.f;
-        for (int e = beg; e < end; ++e) {
-            const int ent = en[e];
-            const int s = ent / K, k = ent - s * K;
-            bool dup = false;                       // the same fine row listed earlier by this coarse row
-            for (int j = 0; j < k; ++j) dup |= (mpa_clamp_idx(kb[(size_t)s * K + j], Nf) == n);
-            if (dup) continue;
-            const T *row = pb + (size_t)s * C;
-            if constexpr (V == 4) {
-                const float4 v = mpa_ld4<T>(row + c);
-                acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
-            } else {
-                acc[0] += mpa_ld1<T>(row + c);
+        // four entries at a time, the entry words first, then their rows, all in flight together (one entry after the
+        // other was two dependent round trips each, plus up to K-1 index loads for the repeat test: the table build
+        // marks the repeats now, bit 31)
+        for (int e0 = beg; e0 < end; e0 += 4) {
+            int ent[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ent[u] = en[min(e0 + u, end - 1)];
+            float4 v[4];
+            float first[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool use = e0 + u < end && ent[u] >= 0;
+                const T *row = pb + (size_t)((ent[u] & 0x7fffffff) / K) * C;
+                if constexpr (V == 4) {
+                    v[u] = use ? mpa_ld4<T>(row + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                } else {
+                    v[u] = make_float4(use ? mpa_ld1<T>(row + c) : 0.f, 0.f, 0.f, 0.f);
+                }
+                first[u] = use ? mpa_ld1<T>(row) : 0.f;
             }
-            div += mpa_ld1<T>(row) != 0.0f ? 1.f : 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc[0] += v[u].x;
+                if constexpr (V == 4) { acc[1] += v[u].y; acc[2] += v[u].z; acc[3] += v[u].w; }
+                div += first[u] != 0.0f ? 1.f : 0.f;
+            }
         }
         if (c == 0) cnt[(size_t)b * Nf + n] = div;
         const float d = div == 0.f ? 1.f : div;
@@ -396,7 +407,7 @@ extern "C" int mpa_upsample_mean_fwd_f32(const float *points, const int64_t *knn
     if (workspace && need && workspace_bytes >= need && ((uintptr_t)workspace & 15) == 0 && !force_atomic) {
         int *rowptr = reinterpret_cast<int *>(workspace);
         int *entries = reinterpret_cast<int *>((char *)workspace + (((size_t)B * (Nf + 1) * 4 + 255) & ~(size_t)255));
-        launch_csr_build(knn_idx, B, Nf, S * K, rowptr, entries, st);
+        launch_csr_build(knn_idx, B, Nf, S * K, rowptr, entries, st, nullptr, K);
         const bool v4 = (C & 3) == 0 && ((((uintptr_t)points | (uintptr_t)out)) & 15) == 0;
         const int per = v4 ? C / 4 : C;
         int lanes = 1;
@@ -453,7 +464,7 @@ extern "C" int mpa_upsample_mean_fwd_bf16(const mpa_bf16 *points, const int64_t 
     if (!workspace || !need || workspace_bytes < need || ((uintptr_t)workspace & 15) != 0) return MPA_EUNSUPPORTED;
     int *rowptr = reinterpret_cast<int *>(workspace);
     int *entries = reinterpret_cast<int *>((char *)workspace + (((size_t)B * (Nf + 1) * 4 + 255) & ~(size_t)255));
-    launch_csr_build(knn_idx, B, Nf, S * K, rowptr, entries, st);
+    launch_csr_build(knn_idx, B, Nf, S * K, rowptr, entries, st, nullptr, K);
     const bf16_t *pb = reinterpret_cast<const bf16_t *>(points);
     bf16_t *ob = reinterpret_cast<bf16_t *>(out);
     const bool v4 = (C & 3) == 0 && ((((uintptr_t)points | (uintptr_t)out)) & 7) == 0;
