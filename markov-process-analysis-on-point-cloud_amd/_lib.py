@@ -153,6 +153,8 @@ SIGNATURES.update({
     "mpa_smooth_loss_bwd_f32": [_vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp, _vp],
     "mpa_pool_max_mean_fwd_f32": [_vp, _i, _i, _i, _vp, _vp, _vp],
     "mpa_pool_max_mean_bwd_f32": [_vp, _vp, _i, _i, _i, _vp, _vp],
+    "mpa_add_n_f32": [_vp, _vp, _i, ctypes.c_longlong, _i, _vp, _vp],
+    "mpa_add_n_bf16": [_vp, _vp, _i, ctypes.c_longlong, _i, _vp, _vp],
 })
 
 for _name, _args in SIGNATURES.items():
@@ -165,7 +167,7 @@ lib.mpa_upsample_workspace_bytes.restype = ctypes.c_size_t
 lib.mpa_version.restype = ctypes.c_int
 # the argument lists above are written against this ABI version of include/mpa_hip.h (MPA_ABI_VERSION): a stale
 # library would take shifted arguments (a stream pointer read as a device array), so refuse it at load time
-ABI_VERSION = 300
+ABI_VERSION = 301
 if lib.mpa_version() != ABI_VERSION:
     raise ImportError("libmpa_hip.so reports ABI version %d, this binding expects %d -- rebuild it "
                       "(make -C markov-process-analysis-on-point-cloud_amd/csrc)" % (lib.mpa_version(), ABI_VERSION))

@@ -11,6 +11,7 @@
 // classification step, and whole passes over the [B*N, 50] logits in part segmentation.  One wave per row; the
 // class axis lives on the lanes.
 #include "mpa_common.h"
+#include "mpa_bf16.h"
 
 namespace {
 
@@ -253,4 +254,64 @@ extern "C" int mpa_pool_max_mean_bwd_f32(const float *grad_out, const int *arg, 
                        C, grad_x);
     MPA_LAUNCH_CHECK();
     return MPA_OK;
+}
+
+// ---- sum of n (<= 8) equally shaped tensors in one pass: the gradient of a tensor that several consumers read
+// (ops.fanout): autograd would add the n contributions pairwise, n - 1 launches that re-read and re-write the running
+// sum; here every contribution is read once and the sum written once (fp32 accumulation, one rounding for bf16 rows).
+namespace {
+struct AddNArgs { const void *src[8]; long long ld[8]; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void add_n_kernel(const AddNArgs a, int n, long long rows, int c4, T *__restrict__ out)
+{
+    const long long count4 = rows * c4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < count4;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / c4;
+        const int c = (int)(i - r * c4) * 4;
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (u < n) v[u] = mpa_ld4<T>(static_cast<const T *>(a.src[u]) + r * a.ld[u] + c);
+        float4 s = v[0];
+#pragma unroll
+        for (int u = 1; u < 8; ++u)
+            if (u < n) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+        mpa_st4<T>(out + 4 * i, s);
+    }
+}
+
+template <typename T>
+int add_n_any(const void *const *srcs, const long long *lds, int n, long long rows, int C, T *out, void *stream)
+{
+    MPA_CLEAR_ERROR();
+    if (!srcs || !out || n < 1 || n > 8 || rows <= 0 || C <= 0) return MPA_EINVAL;
+    if (C % 4 != 0 || ((uintptr_t)out & mpa_vec4_align<T>::mask) != 0) return MPA_EUNSUPPORTED;
+    AddNArgs a;
+    for (int u = 0; u < 8; ++u) {
+        a.src[u] = u < n ? srcs[u] : nullptr;
+        a.ld[u] = u < n ? (lds ? lds[u] : C) : 0;
+        if (u < n && (!srcs[u] || ((uintptr_t)srcs[u] & mpa_vec4_align<T>::mask) != 0 || a.ld[u] < C || a.ld[u] % 4 != 0))
+            return MPA_EUNSUPPORTED;
+    }
+    long long g = (rows * (C / 4) + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(add_n_kernel<T>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, a, n, rows, C / 4, out);
+    MPA_LAUNCH_CHECK();
+    return MPA_OK;
+}
+}  // namespace
+
+extern "C" int mpa_add_n_f32(const float *const *srcs, const long long *lds, int n, long long rows, int C, float *out,
+                             void *stream)
+{
+    return add_n_any<float>(reinterpret_cast<const void *const *>(srcs), lds, n, rows, C, out, stream);
+}
+
+extern "C" int mpa_add_n_bf16(const mpa_bf16 *const *srcs, const long long *lds, int n, long long rows, int C,
+                              mpa_bf16 *out, void *stream)
+{
+    return add_n_any<bf16_t>(reinterpret_cast<const void *const *>(srcs), lds, n, rows, C, reinterpret_cast<bf16_t *>(out),
+                             stream);
 }

@@ -251,11 +251,14 @@ def local_trans_pair(t1, t2, features, idx1, idx2, center, concat=False, kvkv=No
     if t1.usetanh or t2.usetanh:
         outs = t1(features, idx1, None, center=center), t2(features, idx2, None, center=center)
         return torch.cat(outs, 2) if concat else outs
-    qq = ops.linear_stack(center, (t1.q, t2.q), (True, True))
+    # the centres have three readers (query projections, both residuals): one alias each, so that their gradients
+    # meet in one summing launch (ops.fanout) instead of two adds
+    cen_q, cen_1, cen_2 = ops.fanout(center, 3)
+    qq = ops.linear_stack(cen_q, (t1.q, t2.q), (True, True))
     if kvkv is None:        # (LocalMerge hands the projections over when it computed them together with the centres)
         kvkv = ops.linear_stack(features, (t1.k, t1.v, t2.k, t2.v), (True, False, True, False))
     c1, c2 = ops.diffattn_pair(qq, kvkv, idx1, idx2)
-    return finish_group((t1, t2), (c1, c2), (center, center), concat=concat)
+    return finish_group((t1, t2), (c1, c2), (cen_1, cen_2), concat=concat)
 
 
 def centres_and_projections(t1, t2, feature, FPS_idx):
@@ -349,11 +352,12 @@ class LocalMerge(nn.Module):
         cx = index_points(base_xyz, FPS_idx) if FPS_idx is not None else base_xyz
         ctx_x = ops.diffattn_xyz(base_xyz, cx, idx, tx.q.weight, tx.q.bias, tx.k.weight, tx.k.bias, tx.v.weight,
                                  tx.v.bias)
-        qq = ops.linear_stack(fs, (t1.q, t2.q), (True, True))
+        fs_q, fs_1, fs_2 = ops.fanout(fs, 3)           # (three readers of the centres: see local_trans_pair)
+        qq = ops.linear_stack(fs_q, (t1.q, t2.q), (True, True))
         if kvkv is None:
             kvkv = ops.linear_stack(feature, (t1.k, t1.v, t2.k, t2.v), (True, False, True, False))
         c1, c2 = ops.diffattn_pair(qq, kvkv, idx, idx_feature)
-        return finish_group((tx, t1, t2), (ctx_x, c1, c2), (cx, fs, fs), concat=True)
+        return finish_group((tx, t1, t2), (ctx_x, c1, c2), (cx, fs_1, fs_2), concat=True)
 
 
 def _compose(*maps):
@@ -458,33 +462,40 @@ class KeepHighResolutionModulePartSeg(nn.Module):
         # kNNs depend on the coordinates only: ops.GeometryChain advances them on demand, state i's searches
         # sharing a launch with state i+1's sampling (FPS start indices drawn in the reference's order)
         geo_ = ops.GeometryChain(x0, (N // 2, N // 4, N // 8, N // 16), self.la0.knn)
+        # every encoder state has five readers (the next LocalMerge -- the head's mlp for e4 -- and four of the five
+        # Fuse calls): one alias per reader (ops.fanout), so that each state's gradient is summed in one launch
         e0, n0, k0, d0_ = self.la0(xyz=x0, base_xyz=x0, normal=nrm, xyz_flag=True, geometry=geo_.level(0))
+        e0 = ops.fanout(e0, 5)
         g1 = geo_.level(1)
         p0, x1 = g1.fps_idx, g1.xyz
-        e1, n1, k1, _ = self.la1(xyz=x1, base_xyz=x0, normal=n0, feature=e0, FPS_idx=p0, xyz_flag=True, geometry=g1)
+        e1, n1, k1, _ = self.la1(xyz=x1, base_xyz=x0, normal=n0, feature=e0[0], FPS_idx=p0, xyz_flag=True, geometry=g1)
+        e1 = ops.fanout(e1, 5)
         g2 = geo_.level(2)
         p1, x2 = g2.fps_idx, g2.xyz
-        e2, n2, k2, _ = self.la2(xyz=x2, base_xyz=x1, normal=n1, feature=e1, FPS_idx=p1, xyz_flag=False, geometry=g2)
+        e2, n2, k2, _ = self.la2(xyz=x2, base_xyz=x1, normal=n1, feature=e1[0], FPS_idx=p1, xyz_flag=False, geometry=g2)
+        e2 = ops.fanout(e2, 5)
         g3 = geo_.level(3)
         p2, x3 = g3.fps_idx, g3.xyz
-        e3, n3, k3, _ = self.la3(xyz=x3, base_xyz=x2, normal=n2, feature=e2, FPS_idx=p2, xyz_flag=True, geometry=g3)
+        e3, n3, k3, _ = self.la3(xyz=x3, base_xyz=x2, normal=n2, feature=e2[0], FPS_idx=p2, xyz_flag=True, geometry=g3)
+        e3 = ops.fanout(e3, 5)
         g4 = geo_.level(4)
         p3, x4 = g4.fps_idx, g4.xyz
-        e4, n4, k4, _ = self.la4(xyz=x4, base_xyz=x3, normal=n3, feature=e3, FPS_idx=p3, xyz_flag=False, geometry=g4)
+        e4, n4, k4, _ = self.la4(xyz=x4, base_xyz=x3, normal=n3, feature=e3[0], FPS_idx=p3, xyz_flag=False, geometry=g4)
+        e4 = ops.fanout(e4, 5)
 
         geo = dict(FPS_0=p0, FPS_1=p1, FPS_2=p2, FPS_3=p3, knn_0=k0, knn_1=k1, knn_2=k2, knn_3=k3, knn_4=k4,
                    xyz0=x0, xyz1=x1, xyz2=x2, xyz3=x3, xyz4=x4)
         # decoder: upsample -> Linear -> self-state LocalMerge -> cross-state Fuse, coarse to fine
-        d4 = self.mlp(e4)
-        d4 = self.fuse1(N // 16, f0=e0, f1=e1, f2=e2, f3=e3, f4=d4, **geo)[4]
+        d4 = self.mlp(e4[0])
+        d4 = self.fuse1(N // 16, f0=e0[1], f1=e1[1], f2=e2[1], f3=e3[1], f4=d4, **geo)[4]
         d3 = self.la4_up(xyz=x3, base_xyz=x3, normal=n3, feature=self.up_conv4(upsample(d4, k4)))[0]
-        d3 = self.fuse2(N // 8, f0=e0, f1=e1, f2=e2, f3=d3, f4=e4, **geo)[3]
+        d3 = self.fuse2(N // 8, f0=e0[2], f1=e1[2], f2=e2[2], f3=d3, f4=e4[1], **geo)[3]
         d2 = self.la3_up(xyz=x2, base_xyz=x2, normal=n2, feature=self.up_conv3(upsample(d3, k3)))[0]
-        d2 = self.fuse3(N // 4, f0=e0, f1=e1, f2=d2, f3=e3, f4=e4, **geo)[2]
+        d2 = self.fuse3(N // 4, f0=e0[3], f1=e1[3], f2=d2, f3=e3[2], f4=e4[2], **geo)[2]
         d1 = self.la2_up(xyz=x1, base_xyz=x1, normal=n1, feature=self.up_conv2(upsample(d2, k2)))[0]
-        d1 = self.fuse4(N // 2, f0=e0, f1=d1, f2=e2, f3=e3, f4=e4, **geo)[1]
+        d1 = self.fuse4(N // 2, f0=e0[4], f1=d1, f2=e2[3], f3=e3[3], f4=e4[3], **geo)[1]
         d0 = self.la1_up(xyz=x0, base_xyz=x0, normal=n0, feature=self.up_conv1(upsample(d1, k1)))[0]
-        d0 = self.fuse5(N, f0=d0, f1=e1, f2=e2, f3=e3, f4=e4, **geo)[0]
+        d0 = self.fuse5(N, f0=d0, f1=e1[4], f2=e2[4], f3=e3[4], f4=e4[4], **geo)[0]
 
         # per-cloud rows (five global maxima | label embedding) next to every point's conv5 features; the
         # broadcast + concatenation is one op whose backward sums the per-cloud columns with this library's

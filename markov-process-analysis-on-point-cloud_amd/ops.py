@@ -1312,6 +1312,73 @@ def smooth_loss(x, target, eps=0.1, from_logits=False):
     return _SmoothLoss.apply(_f32(x), _i64(target).view(-1), eps, bool(from_logits))
 
 
+class _Fanout(torch.autograd.Function):
+    """x -> n aliases of x, one per consumer; backward: the n gradients summed in ONE launch (mpa_add_n_*)."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.n = n
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        gs = [g for g in grads if g is not None]
+        if len(gs) == 1:
+            return gs[0], None
+        first = gs[0]
+        C = first.shape[-1] if first.dim() else 0
+        rows = first.numel() // C if C else 0
+        lds = [_row_stride(g, C) for g in gs]
+        ok = (first.dtype in (torch.float32, torch.bfloat16) and C and C % 4 == 0 and len(gs) <= 8
+              and all(g.dtype == first.dtype and g.shape == first.shape for g in gs))
+        if not ok:
+            acc = gs[0]
+            for g in gs[1:]:
+                acc = acc + g
+            return acc, None
+        # (a contribution that is a column block of a wider tensor -- one stream of a concatenated gradient -- is read
+        # in place through its row stride)
+        gs = [g if ld else g.contiguous() for g, ld in zip(gs, lds)]
+        out = torch.empty(first.shape, dtype=first.dtype, device=first.device)
+        ptrs = (ctypes.c_void_p * len(gs))(*[g.data_ptr() for g in gs])
+        strides = (ctypes.c_longlong * len(gs))(*[ld or C for ld in lds])
+        align = 16 if first.dtype == torch.float32 else 8
+        if any(g.data_ptr() % align or (ld or C) % 4 for g, ld in zip(gs, lds)):
+            gs = [g.contiguous() for g in gs]
+            ptrs = (ctypes.c_void_p * len(gs))(*[g.data_ptr() for g in gs])
+            strides = (ctypes.c_longlong * len(gs))(*[C] * len(gs))
+        _launch("mpa_add_n_" + _sfx(out), ptrs, strides, len(gs), rows, C, _p(out), _stream())
+        return out, None
+
+
+def _row_stride(t, C):
+    """Row stride (elements) if `t` [..., C] is a set of equally spaced dense rows (a contiguous tensor or a column block
+    of one), else 0."""
+    if t.dim() == 0 or t.stride(-1) != 1 and t.shape[-1] != 1:
+        return 0
+    if t.dim() == 1:
+        return C
+    ld = t.stride(-2)
+    if ld < C:
+        return 0
+    expect = ld
+    for d in range(t.dim() - 2, -1, -1):
+        if t.shape[d] != 1 and t.stride(d) != expect:
+            return 0
+        expect *= t.shape[d]
+    return ld
+
+
+def fanout(x, n):
+    """n aliases of `x` for n consumers (modules that read one tensor several times: a LocalTrans pair's centres feed the
+    query projection and both residuals, the part-seg encoder's states feed four Fuse calls and the next LocalMerge):
+    the consumers' gradients meet in one summing launch instead of autograd's n - 1 pairwise adds.  Values are
+    untouched (views); without a gradient to route it is `(x,) * n`."""
+    if n <= 1 or not (torch.is_grad_enabled() and x.requires_grad) or not x.is_cuda:
+        return (x,) * n
+    return _Fanout.apply(x, n)
+
+
 class _PoolMaxMean(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):

@@ -33,7 +33,7 @@ def test_binding_covers_header():
     bound = set(_lib.SIGNATURES) | {"mpa_version", "mpa_error_string", "mpa_last_hip_error",
                                     "mpa_last_hip_error_string"}
     assert bound == set(declared_symbols())
-    assert _lib.lib.mpa_version() == _lib.ABI_VERSION == 300
+    assert _lib.lib.mpa_version() == _lib.ABI_VERSION == 301
     assert b"invalid" in _lib.lib.mpa_error_string(-1)
 
 
