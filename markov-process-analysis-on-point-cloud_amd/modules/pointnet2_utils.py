@@ -456,7 +456,7 @@ class KeepHighResolutionModulePartSeg(nn.Module):
 
     def forward(self, xyz, normal, label):
         x0 = xyz.permute(0, 2, 1).contiguous()
-        nrm = normal.permute(0, 2, 1).contiguous()
+        nrm = x0 if normal is xyz else normal.permute(0, 2, 1).contiguous()   # (the models pass xyz as `normal`)
         N = x0.shape[1]
         # encoder: four FPS halvings, one LocalMerge per state.  The sampling chain and the xyz-space
         # kNNs depend on the coordinates only: ops.GeometryChain advances them on demand, state i's searches

@@ -217,8 +217,9 @@ class KeepHighResolutionModule(nn.Module):
     LEVELS = (512, 256, 128, 64, 32)
 
     def forward(self, xyz, normal):
+        same = normal is xyz                 # (the shipped models pass the coordinates as `normal`: one transposition)
         xyz = xyz.permute(0, 2, 1).contiguous()
-        normal = normal.permute(0, 2, 1).contiguous()
+        normal = xyz if same else normal.permute(0, 2, 1).contiguous()
         # Every FPS level and every xyz-space kNN depends on the input coordinates only (992 serial FPS
         # iterations on 64 of the 256 CUs): the chain is advanced on demand, state i+1's sampling in the same
         # launch as state i's searches, which keep the rest of the chip busy meanwhile.
