@@ -1004,3 +1004,63 @@ def test_gather_and_stack_matches_separate_ops():
         assert torch.allclose(a.weight.grad, b.weight.grad, rtol=1e-5, atol=1e-5 * float(b.weight.grad.abs().max()))
         if not z:
             assert torch.allclose(a.bias.grad, b.bias.grad, rtol=1e-5, atol=1e-5 * float(b.bias.grad.abs().max()))
+
+
+@pytest.mark.parametrize("K,C,use_fps", [(8, 64, True), (5, 48, True), (16, 96, False), (3, 160, True), (8, 256, False)])
+def test_local_trans_xyz_branch_other_widths_vs_oracle(P, K, C, use_fps):
+    """The xyz branch of LocalTrans (reference modules/pointnet2_utils.py:518-544) at neighbourhood sizes other than 8
+    (the kernels' run-time-K form) and channel counts that are not a multiple of a wave (partly live waves still stage
+    the point's operands) against oracle/ref_cpu.py on the same weights: forward and every parameter gradient."""
+    from oracle import ref_cpu as R
+    from param_fill import unit_cloud
+    B, N, S = 3, 200, 77
+    xyz = unit_cloud(B, N, seed=5)
+    g = torch.Generator().manual_seed(K * 100 + C)
+    fps = torch.stack([torch.randperm(N, generator=g)[:S] for _ in range(B)]) if use_fps else None
+    idx = torch.randint(0, N, (B, S if use_fps else N, K), generator=g)
+    ref = fill_state(R.LocalTrans(3, C, K, residual=True), seed=6).train()
+    got = fill_state(P.LocalTrans(3, C, K, residual=True), seed=6).cuda().train()
+    want = ref(xyz, idx, xyz, FPS_idx=fps, xyz=True)
+    out = got(xyz.cuda(), idx.cuda(), xyz.cuda(), FPS_idx=None if fps is None else fps.cuda(), xyz=True)
+    close(out, want.detach().numpy(), what="out")
+    gy = randn(tuple(want.shape), seed=11)
+    want.backward(gy)
+    out.backward(gy.cuda())
+    gref = {n: p.grad for n, p in ref.named_parameters() if p.grad is not None}
+    gs = max(float(v.abs().max()) for v in gref.values())
+    for n, p in got.named_parameters():
+        if n not in gref:
+            assert p.grad is None, n
+            continue
+        # max over K is a selection: where two of a (point, channel)'s K products are within rounding of each other the
+        # two implementations may route that pair's gradient to different neighbours (tools/lm_probe.py) -- one such pair
+        # among the 150k of the widest case moves three entries of one channel's weights by O(g).  Every entry within
+        # 1e-4 x scale, or at most 1 % of the entries beyond it with the whole tensor within 2e-3 relative L2.
+        d = (p.grad.cpu() - gref[n]).abs()
+        beyond = float((d > TOL * max(1.0, gs)).float().mean())
+        rel = float((p.grad.cpu() - gref[n]).norm() / gref[n].norm().clamp_min(1e-12))
+        assert beyond == 0.0 or (beyond <= 0.01 and rel < 2e-3), (n, beyond, rel)
+
+
+def test_fanout_sums_its_consumers_gradients_in_one_launch(P):
+    """ops.fanout: values untouched, the gradient is the sum of the consumers' gradients -- dense ones and column blocks
+    of a wider tensor (read in place through their row stride), fp32 and bf16 rows."""
+    from mpa_amd import ops
+    for dtype, tol in ((torch.float32, 1e-6), (torch.bfloat16, 2e-2)):
+        x = randn((4, 50, 64), seed=1).cuda().to(dtype).requires_grad_(True)
+        a, b, c, d = ops.fanout(x, 4)
+        assert all(torch.equal(t, x) for t in (a, b, c, d))
+        w = [randn((4, 50, 64), seed=10 + i).cuda().to(dtype) for i in range(2)]
+        wide = randn((4, 50, 192), seed=20).cuda().to(dtype)
+        # consumers: two dense products, one column block of a concatenation, one unused alias
+        y = (a * w[0]).sum() + (b * w[1]).sum() + (torch.cat((c, c.detach(), c.detach()), 2) * wide).sum()
+        y.backward()
+        want = w[0].float() + w[1].float() + wide[..., :64].float()
+        assert float((x.grad.float() - want).abs().max()) <= tol * float(want.abs().max())
+    x = randn((2, 7, 10), seed=3).cuda().requires_grad_(True)          # rows that are not a multiple of four: plain adds
+    a, b = ops.fanout(x, 2)
+    (a.sum() * 2 + b.sum() * 3).backward()
+    assert torch.allclose(x.grad, torch.full_like(x, 5.0))
+    with torch.no_grad():
+        a, b = ops.fanout(x, 2)
+        assert a is x and b is x
