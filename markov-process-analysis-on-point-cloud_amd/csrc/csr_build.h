@@ -2,8 +2,6 @@
 // rowptr [B][N+1] and entries [B][SK] (entry = position in the cloud's idx row), rows in ascending
 // order, entries of a row in no particular order.  Shared by the difference-attention backward
 // (diffattn.hip) and the upsample forward (gather.hip): both turn a scatter-add over idx into a gather.
-// MARK_K > 0 (upsample): idx is [B, S, MARK_K] and an entry whose value already occurs EARLIER in its group of MARK_K
-// gets bit 31 set -- the consumer counts every (group, value) pair once (scatter_ semantics) without going back to idx.
 #pragma once
 #include "mpa_common.h"
 
@@ -49,8 +47,7 @@ constexpr int CSR_QUEUE_INTS = CSR_QUEUE_MAX + 2;
 // build next to independent work (the attention backward's first pass, diffattn.hip).
 __device__ __forceinline__ void csr_build_body(const int64_t *__restrict__ idx, int N, int SK, int range,
                                                int *__restrict__ rowptr, int *__restrict__ entries,
-                                               int *__restrict__ queue, const int bx, const int by, int *csr_lds,
-                                               const int mark_k = 0)
+                                               int *__restrict__ queue, const int bx, const int by, int *csr_lds)
 {
     __shared__ int wave_tot[CSR_TPB / 64];
     constexpr int EPT = 32;                // entries per thread and chunk, all loads in flight at once
@@ -105,25 +102,16 @@ __device__ __forceinline__ void csr_build_body(const int64_t *__restrict__ idx, 
         }
 #pragma unroll
         for (int u = 0; u < EPT; ++u)
-            if (rr[u] >= r0 && rr[u] < r1) {
-                int e = base + u * CSR_TPB + tid;
-                if (mark_k > 0) {
-                    const int k = e % mark_k;
-                    bool dup = false;
-                    for (int j = 1; j <= k; ++j) dup |= (int)mpa_clamp_idx(nb[e - j], N) == rr[u];
-                    if (dup) e |= (int)0x80000000;
-                }
-                en[atomicAdd(&pos[rr[u] - r0], 1)] = e;
-            }
+            if (rr[u] >= r0 && rr[u] < r1) en[atomicAdd(&pos[rr[u] - r0], 1)] = base + u * CSR_TPB + tid;
     }
 }
 
 __global__ __launch_bounds__(CSR_TPB) void csr_build_kernel(const int64_t *__restrict__ idx, int N, int SK, int range,
                                                              int *__restrict__ rowptr, int *__restrict__ entries,
-                                                             int *__restrict__ queue, int mark_k)
+                                                             int *__restrict__ queue)
 {
     extern __shared__ int csr_dyn_lds[];
-    csr_build_body(idx, N, SK, range, rowptr, entries, queue, blockIdx.x, blockIdx.y, csr_dyn_lds, mark_k);
+    csr_build_body(idx, N, SK, range, rowptr, entries, queue, blockIdx.x, blockIdx.y, csr_dyn_lds);
 }
 
 // rows per workgroup of a build over B clouds of N rows: ~256 rows each, >= 256 workgroups in all
@@ -135,11 +123,11 @@ inline int csr_range(int B, int N)
 }
 
 inline void launch_csr_build(const int64_t *idx, int B, int N, int SK, int *rowptr, int *entries, hipStream_t st,
-                             int *queue = nullptr, int mark_k = 0)
+                             int *queue = nullptr)
 {
     const int range = csr_range(B, N);
     hipLaunchKernelGGL(csr_build_kernel, dim3(mpa_ceil_div(N, range), B), dim3(CSR_TPB),
-                       (size_t)2 * range * sizeof(int), st, idx, N, SK, range, rowptr, entries, queue, mark_k);
+                       (size_t)2 * range * sizeof(int), st, idx, N, SK, range, rowptr, entries, queue);
 }
 
 }  // namespace

@@ -130,24 +130,38 @@ __global__ __launch_bounds__(TPB) void upsample_gather_kernel(const T *__restric
         for (int u = 0; u < V; ++u) acc[u] = 0.f;
         float div = 0.f;
         // four entries at a time, the entry words first, then their rows, all in flight together (one entry after the
-        // other was two dependent round trips each, plus up to K-1 index loads for the repeat test: the table build
-        // marks the repeats now, bit 31)
+        // other was two dependent round trips each, plus up to K-1 index loads for the repeat test).  A coarse row that
+        // lists this fine row more than once counts once (scatter_ semantics): its entries share their coarse row, so
+        // an entry is skipped when an earlier entry of the list has the same one -- compared in registers inside the
+        // chunk, against the (L1-resident) earlier chunks for the few rows with more than four entries
         for (int e0 = beg; e0 < end; e0 += 4) {
-            int ent[4];
+            int srow[4];
+            bool use[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) ent[u] = en[min(e0 + u, end - 1)];
+            for (int u = 0; u < 4; ++u) {
+                srow[u] = en[min(e0 + u, end - 1)] / K;
+                use[u] = e0 + u < end;
+            }
+#pragma unroll
+            for (int u = 1; u < 4; ++u)
+#pragma unroll
+                for (int w = 0; w < u; ++w) use[u] = use[u] && srow[w] != srow[u];
+            for (int ep = beg; ep < e0; ++ep) {
+                const int sp = en[ep] / K;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) use[u] = use[u] && sp != srow[u];
+            }
             float4 v[4];
             float first[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const bool use = e0 + u < end && ent[u] >= 0;
-                const T *row = pb + (size_t)((ent[u] & 0x7fffffff) / K) * C;
+                const T *row = pb + (size_t)srow[u] * C;
                 if constexpr (V == 4) {
-                    v[u] = use ? mpa_ld4<T>(row + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    v[u] = use[u] ? mpa_ld4<T>(row + c) : make_float4(0.f, 0.f, 0.f, 0.f);
                 } else {
-                    v[u] = make_float4(use ? mpa_ld1<T>(row + c) : 0.f, 0.f, 0.f, 0.f);
+                    v[u] = make_float4(use[u] ? mpa_ld1<T>(row + c) : 0.f, 0.f, 0.f, 0.f);
                 }
-                first[u] = use ? mpa_ld1<T>(row) : 0.f;
+                first[u] = use[u] ? mpa_ld1<T>(row) : 0.f;
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -407,7 +421,7 @@ extern "C" int mpa_upsample_mean_fwd_f32(const float *points, const int64_t *knn
     if (workspace && need && workspace_bytes >= need && ((uintptr_t)workspace & 15) == 0 && !force_atomic) {
         int *rowptr = reinterpret_cast<int *>(workspace);
         int *entries = reinterpret_cast<int *>((char *)workspace + (((size_t)B * (Nf + 1) * 4 + 255) & ~(size_t)255));
-        launch_csr_build(knn_idx, B, Nf, S * K, rowptr, entries, st, nullptr, K);
+        launch_csr_build(knn_idx, B, Nf, S * K, rowptr, entries, st);
         const bool v4 = (C & 3) == 0 && ((((uintptr_t)points | (uintptr_t)out)) & 15) == 0;
         const int per = v4 ? C / 4 : C;
         int lanes = 1;
@@ -464,7 +478,7 @@ extern "C" int mpa_upsample_mean_fwd_bf16(const mpa_bf16 *points, const int64_t 
     if (!workspace || !need || workspace_bytes < need || ((uintptr_t)workspace & 15) != 0) return MPA_EUNSUPPORTED;
     int *rowptr = reinterpret_cast<int *>(workspace);
     int *entries = reinterpret_cast<int *>((char *)workspace + (((size_t)B * (Nf + 1) * 4 + 255) & ~(size_t)255));
-    launch_csr_build(knn_idx, B, Nf, S * K, rowptr, entries, st, nullptr, K);
+    launch_csr_build(knn_idx, B, Nf, S * K, rowptr, entries, st);
     const bf16_t *pb = reinterpret_cast<const bf16_t *>(points);
     bf16_t *ob = reinterpret_cast<bf16_t *>(out);
     const bool v4 = (C & 3) == 0 && ((((uintptr_t)points | (uintptr_t)out)) & 7) == 0;

@@ -846,7 +846,8 @@ def test_upsample_paths_match_oracle(B, S, K, r, C):
     pts = torch.randn(B, S, C, generator=gen)
     pts[:, ::5, 0] = 0.0
     idx = torch.randint(0, S * r, (B, S, K), generator=gen)
-    idx[:, :, 1] = idx[:, :, 0]                        # a coarse row listing a fine point twice
+    idx[:, :, 1] = idx[:, :, 0]                        # a coarse row listing a fine point twice ...
+    idx[:, ::2, K - 1] = idx[:, ::2, 0]                # ... and a third time, in a slot that is not adjacent
     want = R.upsample(pts, idx, scale_ratio=r).numpy()
     p, i = pts.cuda(), idx.cuda()
     need = int(_lib.lib.mpa_upsample_workspace_bytes(B, S, K, S * r))
