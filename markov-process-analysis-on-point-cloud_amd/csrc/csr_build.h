@@ -1,6 +1,7 @@
 // Inverted neighbour table (CSR) of an index tensor idx [B, SK] with values in [0, N): for every cloud,
 // rowptr [B][N+1] and entries [B][SK] (entry = position in the cloud's idx row), rows in ascending
-// order, entries of a row in no particular order.  Shared by the difference-attention backward
+// order, entries of a row in no particular order (sort_rows: ascending, for rows of up to CSR_SORT_MAX entries).
+// Shared by the difference-attention backward
 // (diffattn.hip) and the upsample forward (gather.hip): both turn a scatter-add over idx into a gather.
 #pragma once
 #include "mpa_common.h"
@@ -14,6 +15,7 @@ constexpr int CSR_MAX_N = 65536;       // rows per cloud; a workgroup's row rang
 // split over CSR_RANGES workgroups per cloud), counts the entries below its range for the global
 // offset, scans and fills its rows' lists.
 constexpr int CSR_TPB = 256;
+constexpr int CSR_SORT_MAX = 32;       // rows up to this many entries are sorted after the fill (see csr_build_body)
 
 __device__ __forceinline__ int block_exclusive_scan(int v, int *wave_tot, int &total)
 {
@@ -47,7 +49,8 @@ constexpr int CSR_QUEUE_INTS = CSR_QUEUE_MAX + 2;
 // build next to independent work (the attention backward's first pass, diffattn.hip).
 __device__ __forceinline__ void csr_build_body(const int64_t *__restrict__ idx, int N, int SK, int range,
                                                int *__restrict__ rowptr, int *__restrict__ entries,
-                                               int *__restrict__ queue, const int bx, const int by, int *csr_lds)
+                                               int *__restrict__ queue, const int bx, const int by, int *csr_lds,
+                                               const bool sort_rows = false)
 {
     __shared__ int wave_tot[CSR_TPB / 64];
     constexpr int EPT = 32;                // entries per thread and chunk, all loads in flight at once
@@ -104,14 +107,35 @@ __device__ __forceinline__ void csr_build_body(const int64_t *__restrict__ idx, 
         for (int u = 0; u < EPT; ++u)
             if (rr[u] >= r0 && rr[u] < r1) en[atomicAdd(&pos[rr[u] - r0], 1)] = base + u * CSR_TPB + tid;
     }
+    // sort_rows (the upsample forward's tables): rows of up to CSR_SORT_MAX entries are put in ascending entry order -- the
+    // consumer sums a row's entries in list order, so its sums no longer depend on the order the cursors' atomics
+    // retired and the part-seg forward is reproducible run to run (tools/determinism_probe.py); longer rows -- hubs --
+    // keep the order they got.  The attention backward's tables skip it: 0.5 % of a cls step, and its sums meet float
+    // atomics further down anyway.
+    if (!sort_rows) return;
+    __syncthreads();
+    for (int r = tid * per; r < min(r1 - r0, (tid + 1) * per); ++r) {
+        const int n = cnt[r];
+        if (n < 2 || n > CSR_SORT_MAX) continue;
+        int *row = en + rp[r0 + r];
+        for (int i = 1; i < n; ++i) {
+            const int v = row[i];
+            int j = i - 1;
+            while (j >= 0 && row[j] > v) {
+                row[j + 1] = row[j];
+                --j;
+            }
+            row[j + 1] = v;
+        }
+    }
 }
 
 __global__ __launch_bounds__(CSR_TPB) void csr_build_kernel(const int64_t *__restrict__ idx, int N, int SK, int range,
                                                              int *__restrict__ rowptr, int *__restrict__ entries,
-                                                             int *__restrict__ queue)
+                                                             int *__restrict__ queue, int sort_rows)
 {
     extern __shared__ int csr_dyn_lds[];
-    csr_build_body(idx, N, SK, range, rowptr, entries, queue, blockIdx.x, blockIdx.y, csr_dyn_lds);
+    csr_build_body(idx, N, SK, range, rowptr, entries, queue, blockIdx.x, blockIdx.y, csr_dyn_lds, sort_rows != 0);
 }
 
 // rows per workgroup of a build over B clouds of N rows: ~256 rows each, >= 256 workgroups in all
@@ -123,11 +147,11 @@ inline int csr_range(int B, int N)
 }
 
 inline void launch_csr_build(const int64_t *idx, int B, int N, int SK, int *rowptr, int *entries, hipStream_t st,
-                             int *queue = nullptr)
+                             int *queue = nullptr, bool sort_rows = false)
 {
     const int range = csr_range(B, N);
     hipLaunchKernelGGL(csr_build_kernel, dim3(mpa_ceil_div(N, range), B), dim3(CSR_TPB),
-                       (size_t)2 * range * sizeof(int), st, idx, N, SK, range, rowptr, entries, queue);
+                       (size_t)2 * range * sizeof(int), st, idx, N, SK, range, rowptr, entries, queue, sort_rows ? 1 : 0);
 }
 
 }  // namespace

@@ -421,7 +421,7 @@ extern "C" int mpa_upsample_mean_fwd_f32(const float *points, const int64_t *knn
     if (workspace && need && workspace_bytes >= need && ((uintptr_t)workspace & 15) == 0 && !force_atomic) {
         int *rowptr = reinterpret_cast<int *>(workspace);
         int *entries = reinterpret_cast<int *>((char *)workspace + (((size_t)B * (Nf + 1) * 4 + 255) & ~(size_t)255));
-        launch_csr_build(knn_idx, B, Nf, S * K, rowptr, entries, st);
+        launch_csr_build(knn_idx, B, Nf, S * K, rowptr, entries, st, nullptr, true);
         const bool v4 = (C & 3) == 0 && ((((uintptr_t)points | (uintptr_t)out)) & 15) == 0;
         const int per = v4 ? C / 4 : C;
         int lanes = 1;
@@ -478,7 +478,7 @@ extern "C" int mpa_upsample_mean_fwd_bf16(const mpa_bf16 *points, const int64_t 
     if (!workspace || !need || workspace_bytes < need || ((uintptr_t)workspace & 15) != 0) return MPA_EUNSUPPORTED;
     int *rowptr = reinterpret_cast<int *>(workspace);
     int *entries = reinterpret_cast<int *>((char *)workspace + (((size_t)B * (Nf + 1) * 4 + 255) & ~(size_t)255));
-    launch_csr_build(knn_idx, B, Nf, S * K, rowptr, entries, st);
+    launch_csr_build(knn_idx, B, Nf, S * K, rowptr, entries, st, nullptr, true);
     const bf16_t *pb = reinterpret_cast<const bf16_t *>(points);
     bf16_t *ob = reinterpret_cast<bf16_t *>(out);
     const bool v4 = (C & 3) == 0 && ((((uintptr_t)points | (uintptr_t)out)) & 7) == 0;
